@@ -1,0 +1,154 @@
+/*
+ * include/wann.h -- C ABI of the MI355X-native window-filtered ANN engine (libwann.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of JoshEngels/RangeFilteredANN that this
+ * repository accelerates: `batch_search` on the reference's window-search index classes.
+ * Plain pointers and sizes only (no torch / pybind11 / STL types); the pybind11 module
+ * `window_ann` (rangefilteredann_amd/csrc/window_ann_pybind.cpp) is a thin shim over it and
+ * re-exports the reference's Python names.  All file:line citations are into the reference.
+ *
+ *   wann_index_create        replaces the constructors of
+ *       PrefilterIndex<T,Point>                              python_bindings.cpp:111-117, src/prefiltering.h:76-122
+ *       PostfilterVamanaIndex<T,Point>                       python_bindings.cpp:129-134, src/postfilter_vamana.h:91-124
+ *       RangeFilterTreeIndex<T,Point>                        python_bindings.cpp:119-127, src/range_filter_tree.h:50-59
+ *       RangeFilterTreeIndex<T,Point,PostfilterVamanaIndex>  python_bindings.cpp:136-145, src/range_filter_tree.h:50-59,129-189
+ *       SuperOptimizedPostfilterTree<..,PostfilterVamanaIndex> python_bindings.cpp:147-157, src/super_optimized_postfilter_tree.h:45-58,118-171
+ *   wann_batch_search        replaces <Index>::batch_search
+ *       src/range_filter_tree.h:62-96, src/super_optimized_postfilter_tree.h:60-87,
+ *       src/postfilter_vamana.h:191-219, src/prefiltering.h:124-146
+ *   wann_batch_search_device the same call with queries / ranges / outputs already resident in HBM
+ *   wann_query_params        QueryParams   ParlayANN/algorithms/utils/types.h:115-140, python_bindings.cpp:204-209
+ *   wann_build_params        BuildParams   ParlayANN/algorithms/utils/types.h:77-112,  python_bindings.cpp:211-213
+ *
+ * Error model: functions return 0 on success, non-zero on failure; wann_last_error() gives the
+ * message (thread local).  There is NO CPU fallback: every entry point that computes fails with
+ * WANN_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef WANN_H
+#define WANN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WANN_ABI_VERSION 1
+
+enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP = 3, WANN_ERR_IO = 4,
+       WANN_ERR_UNSUPPORTED = 5 };
+
+/* distance: Euclidian_Point (squared L2, euclidian_point.h:62-75) / Mips_Point (-<q,p>, mips_point.h:60-76) */
+enum { WANN_METRIC_L2 = 0, WANN_METRIC_MIPS = 1 };
+/* element type of points/queries (python_bindings.cpp:232-237); the device path is float32 */
+enum { WANN_DTYPE_F32 = 0, WANN_DTYPE_U8 = 1, WANN_DTYPE_I8 = 2 };
+/* index classes */
+enum {
+  WANN_KIND_PREFILTER = 0,      /* PrefilterIndex                                   */
+  WANN_KIND_POSTFILTER = 1,     /* PostfilterVamanaIndex (one graph, raw point ids)  */
+  WANN_KIND_TREE_PREFILTER = 2, /* RangeFilterTreeIndex with PrefilterIndex leaves   */
+  WANN_KIND_TREE_VAMANA = 3,    /* VamanaRangeFilterTreeIndex (B-ary window search tree) */
+  WANN_KIND_SUPER = 4           /* SuperOptimizedPostfilterTreeIndex                 */
+};
+
+typedef struct {
+  int64_t k;                      /* QueryParams::k                      */
+  int64_t beam_width;             /* QueryParams::beamSize               */
+  double cut;                     /* QueryParams::cut (inactive on the post-filter path) */
+  int64_t limit;                  /* visit limit                         */
+  int64_t degree_limit;
+  int64_t final_beam_multiply;
+  int64_t postfiltering_max_beam;
+  int32_t has_min_query_to_bucket_ratio; /* std::optional<float>::has_value() */
+  float min_query_to_bucket_ratio;
+  int32_t verbose;                /* accepted, ignored                   */
+} wann_query_params;
+
+typedef struct {
+  int64_t max_degree;     /* R */
+  int64_t limit;          /* L (build beam) */
+  double alpha;
+  const char *cache_path; /* graph cache prefix, "" / NULL = none (postfilter_vamana.h:54-78,126-132) */
+} wann_build_params;
+
+/* Work counters of the last batch_search (exact, produced by the kernels). */
+typedef struct {
+  int64_t beam_searches; /* raw beam searches (all doubling rounds + final re-searches) */
+  int64_t hops;          /* adjacency rows expanded (= visited nodes)                   */
+  int64_t dist_cmps;     /* vectors scored by graph search                              */
+  int64_t brute_rows;    /* vectors scored by brute-force scans                         */
+  int64_t label_reads;   /* labels read by the post filter                              */
+  int64_t rounds;        /* kernel launches of the beam-search kernel                   */
+  double device_ms;      /* HIP-event time of the whole call on its stream              */
+  double search_kernel_ms; /* HIP-event time summed over beam-search kernel launches    */
+} wann_counters;
+
+typedef struct wann_index wann_index;
+
+int wann_abi_version(void);
+const char *wann_last_error(void);
+/* number of usable gfx950 devices (0 when none); never initialises a context */
+int wann_device_count(void);
+
+/* Build (or load from the graph cache) an index and make it resident in the HBM of `device`.
+ * points: (n,d) row-major of `dtype`; labels: (n) float32.  cutoff / split_factor /
+ * shift_factor as in the reference constructors (ignored by kinds that have none).
+ * build_threads <= 0: PARLAY_NUM_THREADS if set, else all host cores. */
+wann_index *wann_index_create(int kind, int metric, int dtype, const void *points, int64_t n,
+                              int64_t d, const float *labels, int32_t cutoff, double split_factor,
+                              double shift_factor, const wann_build_params *bp, int device,
+                              int build_threads);
+void wann_index_destroy(wann_index *index);
+
+/* Host-buffer call (the reference's boundary: numpy in, numpy out).  ranges = nq x 2 float32
+ * (lo, hi), bounds inclusive (range_filter_tree.h:61).  method: "optimized_postfilter",
+ * "three_split", anything else = fenwick (range_filter_tree.h:76-82); ignored by non-tree kinds.
+ * ids: nq x k uint32, dists: nq x k float32, caller allocated. */
+int wann_batch_search(wann_index *index, const void *queries, const float *ranges, int64_t nq,
+                      const char *method, const wann_query_params *qp, uint32_t *ids, float *dists);
+
+/* Device-buffer call: same semantics, every pointer is device memory on the index's device;
+ * `query_id_base` is the global row number of queries[0] (the reference uses the query's row
+ * number as its "own id", beamSearch.h:128 + range_filter_tree.h:71-72, so a query shard must
+ * keep its global numbering).  Runs on `hip_stream` (a hipStream_t, NULL = default stream) and
+ * returns after the stream work is complete. */
+int wann_batch_search_device(wann_index *index, const void *d_queries, const float *d_ranges,
+                             int64_t nq, int64_t query_id_base, const char *method,
+                             const wann_query_params *qp, uint32_t *d_ids, float *d_dists,
+                             void *hip_stream);
+
+int wann_get_counters(const wann_index *index, wann_counters *out);
+
+/* Introspection (tests, tools). */
+int64_t wann_num_points(const wann_index *index);
+int64_t wann_dim(const wann_index *index);
+int64_t wann_num_levels(const wann_index *index);
+int64_t wann_level_size(const wann_index *index, int64_t level);
+int wann_partition_range(const wann_index *index, int64_t level, int64_t idx, int64_t *start, int64_t *end);
+/* copy partition graph out in the reference's in-memory layout: n x (R+1) int32, slot 0 = degree */
+int wann_partition_graph(const wann_index *index, int64_t level, int64_t idx, int32_t *rows, int64_t cap_rows);
+int64_t wann_device_bytes(const wann_index *index);
+
+/* Graph-cache tool: build (host, multi-threaded) and save only the cache files of the
+ * partitions p with p % nshards == shard, without creating a device index.  Used to split the
+ * build of one index over the ranks of a multi-GPU job that share a cache directory. */
+int wann_build_cache_shard(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
+                           const float *labels, int32_t cutoff, double split_factor,
+                           double shift_factor, const wann_build_params *bp, int shard, int nshards,
+                           int build_threads);
+
+/* Raw kernels, exported for parity tests and micro-benchmarks (device pointers). */
+/* one beam search per query over ONE graph given in the reference's layout (host pointers;
+ * the call uploads, runs the production kernel and downloads). */
+int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d,
+                         const int32_t *graph_rows /* n x (maxdeg+1) */, int64_t maxdeg,
+                         int64_t subset_start, int64_t subset_n, const float *queries, int64_t nq,
+                         const int64_t *query_ids, int64_t beam, int64_t limit,
+                         int64_t degree_limit, int32_t *out_ids /* nq x beam */,
+                         float *out_dists /* nq x beam */, int32_t *out_sizes /* nq */,
+                         int64_t *out_hops /* nq */, int64_t *out_dist_cmps /* nq */, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WANN_H */

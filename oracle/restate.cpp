@@ -94,6 +94,10 @@ class Pool {
     for (auto &t : workers_) t.join();
   }
   void ensure(int want) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      birth_epoch_ = epoch_;  // new workers must not mistake an old epoch for a posted job
+    }
     while ((int)workers_.size() < want) {
       int id = (int)workers_.size();
       workers_.emplace_back([this, id] { loop(id); });
@@ -110,7 +114,11 @@ class Pool {
     in_parallel_ = false;
   }
   void loop(int id) {
-    uint64_t seen = 0;
+    uint64_t seen;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      seen = birth_epoch_;
+    }
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(mu_);
@@ -134,7 +142,7 @@ class Pool {
   int64_t n_ = 0, chunk_ = 1;
   std::atomic<int64_t> next_{0};
   int active_workers_ = 0, pending_ = 0;
-  uint64_t epoch_ = 0;
+  uint64_t epoch_ = 0, birth_epoch_ = 0;
   bool stop_ = false;
   static thread_local bool in_parallel_;
 };

@@ -1,0 +1,158 @@
+// wann_device.h -- structures shared by the host side (wann_host.cpp) and the gfx950 kernels
+// (wann_kernels.hip).  Device index layout in HBM (see DESIGN.md "Data layout"):
+//
+//   points   float[n][stride]      label-sorted vectors, rows zero padded to 64 B; shared by every
+//                                  partition (a partition is a contiguous slice of the sorted order,
+//                                  reference: range_filter_tree.h:115-127 subset[i] = start + i)
+//   labels   float[n]              sorted labels
+//   decoding uint32[n]             sorted index -> original point id (tree_utils.h:85)
+//   graph    int32[rows][rs]       adjacency pool: one row per (partition, local node), rs = maxdeg
+//                                  rounded up to 16 ints so every row is 64-B aligned; local
+//                                  neighbour ids packed at the front, -1 padded (reference in-memory
+//                                  layout: (maxdeg+1) ints, slot 0 = degree, graph.h:122-124)
+//   parts    PartDesc[]            per partition: first pool row, sorted-order start, size
+#pragma once
+#include <stdint.h>
+
+namespace wann {
+
+struct PartDesc {
+  int64_t row_base;  // first row of this partition in the adjacency pool
+  int32_t start;     // sorted index of local node 0
+  int32_t n;         // number of nodes
+};
+
+struct IndexView {
+  const float *points;
+  const float *labels;
+  const uint32_t *decoding;
+  const int32_t *graph;
+  const PartDesc *parts;
+  // stand-alone PrefilterIndex (prefiltering.h:33-36)
+  const float *fv_sorted;
+  const int32_t *fi_sorted;
+  // window search tree shape (range_filter_tree.h:103): level l has level_nb[l] buckets whose
+  // offsets are wst_off[wst_ptr[l] .. wst_ptr[l] + level_nb[l]] (inclusive end)
+  const int64_t *wst_off;
+  const int64_t *wst_ptr;
+  const int64_t *level_part0;  // index of the first partition of level l in parts[]
+  const int64_t *level_nb;
+  // super tree (super_optimized_postfilter_tree.h:90-91)
+  const int64_t *sup_size;
+  const int64_t *sup_shift;
+  int64_t n;
+  int32_t d, stride, rs, maxdeg, metric, kind, nlevels, cutoff, split, vamana_leaves;
+};
+
+enum { T_EMPTY = 0, T_GRAPH = 1, T_BRUTE = 2, T_BRUTE_GATHER = 3 };
+enum { M_OPTIMIZED = 0, M_THREE_SPLIT = 1, M_FENWICK = 2 };
+
+// One unit of device work: search partition `part` (T_GRAPH) or scan sorted rows [a,b) (T_BRUTE)
+// for query `query` with label window [lo,hi].
+struct Task {
+  int32_t query;
+  int32_t mode;
+  int32_t part;
+  int32_t flags;
+  int64_t a, b;
+  float lo, hi;
+};
+
+struct Counters {
+  unsigned long long beam_searches, hops, dist_cmps, brute_rows, label_reads, unsupported;
+};
+
+struct RouteArgs {
+  IndexView ix;
+  const float *ranges;  // nq x 2
+  int64_t nq;
+  int32_t method;
+  int32_t k;
+  int32_t beam, max_beam;
+  int32_t has_ratio;
+  float ratio;
+  Task *tasks;       // [nq]
+  int32_t *graph_list, *graph_count;
+  int32_t *brute_list, *brute_count;
+  Counters *ctr;
+};
+
+struct SearchArgs {
+  IndexView ix;
+  const float *queries;  // (nq, d) row-major, unpadded
+  int64_t qid_base;
+  const Task *tasks;
+  const int32_t *list;
+  const int32_t *list_count;
+  int32_t *cursor;
+  int32_t B;     // beam of this round
+  int32_t bits;  // log2 of the seen-filter size (beamSearch.h:66)
+  int32_t k;
+  int64_t limit;
+  int32_t degree_limit;
+  int32_t is_final;      // final_beam_multiply re-search: always done afterwards
+  int32_t can_double;    // 2*B < postfiltering_max_beam
+  int32_t wants_final;   // final beam > B  (postfilter_vamana.h:173-181)
+  int32_t *next_list, *next_count;
+  int32_t *final_list, *final_count;
+  unsigned long long *out_key;  // [ntasks][k]  (fkey(dist) << 32 | sorted id)
+  int32_t *out_cnt;             // [ntasks]
+  int32_t *g_table;             // per wave slot seen-filter when it does not fit the LDS
+  unsigned long long *g_beam;   // per wave slot beam when it does not fit the LDS
+  int64_t g_beam_cap;
+  Counters *ctr;
+  // raw mode (wann_raw_beam_search): dump the whole beam instead of the filtered top-k
+  int32_t raw;
+  int32_t *raw_ids;
+  float *raw_dists;
+  int32_t *raw_sizes;
+  long long *raw_hops, *raw_cmps;
+  const long long *raw_qids;  // raw mode: Point::id() of each query
+  unsigned int *trace;        // debug: per wave slot progress marker in host-visible memory (or null)
+};
+
+struct BruteArgs {
+  IndexView ix;
+  const float *queries;
+  const Task *tasks;
+  const int32_t *list;
+  const int32_t *list_count;
+  int32_t *cursor;
+  int32_t k;
+  unsigned long long *out_key;
+  int32_t *out_cnt;
+  Counters *ctr;
+};
+
+struct FinalizeArgs {
+  IndexView ix;
+  const Task *tasks;
+  const unsigned long long *out_key;
+  const int32_t *out_cnt;
+  int64_t nq;
+  int32_t k;
+  int32_t decode;
+  uint32_t pad_id;
+  uint32_t *ids;
+  float *dists;
+};
+
+// launchers implemented in wann_kernels.hip (all asynchronous on `stream`)
+struct LaunchCfg {
+  int blocks;
+  int lds_table;  // 1: seen-filter in LDS
+  int lds_beam;   // 1: beam in LDS
+};
+int launch_route(const RouteArgs &a, void *stream);
+int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);
+int launch_brute(const BruteArgs &a, int blocks, void *stream);
+int launch_finalize(const FinalizeArgs &a, void *stream);
+// how many bytes of LDS one wave of k_search needs for beam B / table bits / stride
+int search_lds_bytes_per_wave(int B, int bits, int stride, int lds_table, int lds_beam);
+const char *launch_last_error();
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxLdsBeam = 2048;  // beams up to this size live in the LDS (16 KiB per wave)
+constexpr int kMaxLdsBits = 12;    // seen-filters up to 2^12 entries live in the LDS (16 KiB per wave)
+
+}  // namespace wann

@@ -1,0 +1,765 @@
+// wann_host.cpp -- C ABI (include/wann.h) of the MI355X window-filtered ANN engine: device
+// residency of the index, the batch_search driver (routing -> brute scans -> doubling rounds of
+// the beam-search kernel -> final re-search -> finalize) and the introspection entry points.
+//
+// There is no CPU search path in this library: every compute entry point needs a gfx950 device
+// and fails loudly otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/wann.h"
+#include "wann_build.h"
+#include "wann_device.h"
+
+using namespace wann;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+#define HIP_CHECK(expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    release();
+    HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+    cap = n;
+  }
+  void upload(const std::vector<T> &v) {
+    ensure(v.size());
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  size_t bytes() const { return cap * sizeof(T); }
+};
+
+int usable_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int hash_bits(int64_t beam) {  // beamSearch.h:66
+  return std::max<int>(10, (int)std::ceil(std::log2((double)(beam * beam))) - 2);
+}
+
+// reference in-memory rows -> device rows: rs ints per row, neighbours packed, -1 padded
+void convert_rows(const HostGraph &g, int rs, int32_t *out) {
+  for (int64_t i = 0; i < g.n; i++) {
+    const int32_t *r = g.row(i);
+    int32_t *o = out + i * rs;
+    const int deg = r[0];
+    if (deg < 0 || deg > g.maxdeg || deg > rs) throw std::runtime_error("graph row degree out of range");
+    for (int j = 0; j < deg; j++) {
+      if (r[1 + j] < 0 || r[1 + j] >= g.n) throw std::runtime_error("graph edge out of range");
+      o[j] = r[1 + j];  // a row may list a node twice (reference-built graphs do); the kernel copes
+    }
+    for (int j = deg; j < rs; j++) o[j] = -1;
+  }
+}
+
+constexpr int kInts = 160;
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+constexpr int kMaxRounds = 30;
+
+struct Workspace {
+  DevBuf<Task> tasks;
+  DevBuf<int32_t> list_a, list_b, list_final, list_brute, ints, out_cnt, g_table;
+  DevBuf<unsigned long long> out_key, g_beam;
+  DevBuf<Counters> ctr;
+  DevBuf<float> q_stage, r_stage, dist_stage;
+  DevBuf<uint32_t> id_stage;
+  int32_t *h_ints = nullptr;  // pinned
+  Counters *h_ctr = nullptr;  // pinned
+  std::vector<hipEvent_t> ev;
+  ~Workspace() {
+    if (h_ints) (void)hipHostFree(h_ints);
+    if (h_ctr) (void)hipHostFree(h_ctr);
+    for (auto e : ev) (void)hipEventDestroy(e);
+  }
+  void ensure(int64_t nq, int k) {
+    tasks.ensure(nq);
+    list_a.ensure(nq);
+    list_b.ensure(nq);
+    list_final.ensure(nq);
+    list_brute.ensure(nq);
+    ints.ensure(kInts);
+    out_cnt.ensure(nq);
+    out_key.ensure((size_t)nq * k);
+    ctr.ensure(1);
+    if (!h_ints) HIP_CHECK(hipHostMalloc((void **)&h_ints, kInts * sizeof(int32_t)));
+    if (!h_ctr) HIP_CHECK(hipHostMalloc((void **)&h_ctr, sizeof(Counters)));
+    while (ev.size() < 2 + 4 * kMaxRounds) {
+      hipEvent_t e;
+      HIP_CHECK(hipEventCreate(&e));
+      ev.push_back(e);
+    }
+  }
+};
+
+}  // namespace
+
+struct wann_index {
+  HostIndex H;
+  int device = 0;
+  int num_cus = 256;
+  DevBuf<float> d_points, d_labels, d_fv;
+  DevBuf<uint32_t> d_decoding;
+  DevBuf<int32_t> d_graph, d_fi;
+  DevBuf<PartDesc> d_parts;
+  DevBuf<int64_t> d_wst_off, d_wst_ptr, d_level_part0, d_level_nb, d_sup_size, d_sup_shift;
+  std::vector<PartDesc> parts;
+  std::vector<int64_t> level_part0;
+  IndexView view{};
+  int64_t device_bytes = 0;
+  Workspace ws;
+  hipStream_t own_stream = nullptr;
+  wann_counters last{};
+  std::mutex mu;
+  ~wann_index() {
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+};
+
+namespace {
+
+void upload_index(wann_index &I) {
+  HostIndex &H = I.H;
+  const BuildSpec &s = H.spec;
+  HIP_CHECK(hipSetDevice(I.device));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, I.device));
+  I.num_cus = prop.multiProcessorCount;
+  std::string arch = prop.gcnArchName;
+  if (arch.rfind("gfx950", 0) != 0)
+    throw HipError("device " + std::to_string(I.device) + " is " + arch + ", this library holds gfx950 code only");
+  HIP_CHECK(hipStreamCreateWithFlags(&I.own_stream, hipStreamNonBlocking));
+
+  IndexView &v = I.view;
+  v.n = s.n;
+  v.d = (int32_t)s.d;
+  v.stride = (int32_t)s.stride;
+  v.metric = s.metric;
+  v.kind = s.kind;
+  v.cutoff = s.cutoff;
+  v.split = (int32_t)s.split_factor;
+  v.vamana_leaves = H.vamana_leaves ? 1 : 0;
+  v.maxdeg = (int32_t)s.R;
+  v.rs = (int32_t)(((s.R + 15) / 16) * 16);
+  v.nlevels = (int32_t)H.levels.size();
+
+  I.d_points.upload(H.pts);
+  I.d_labels.upload(H.labels);
+  I.d_decoding.upload(H.decoding);
+  v.points = I.d_points.p;
+  v.labels = I.d_labels.p;
+  v.decoding = I.d_decoding.p;
+  if (s.kind == WANN_KIND_PREFILTER) {
+    I.d_fv.upload(H.fv_sorted);
+    I.d_fi.upload(H.fi_sorted);
+    v.fv_sorted = I.d_fv.p;
+    v.fi_sorted = I.d_fi.p;
+  }
+  // partitions + adjacency pool
+  int64_t rows = 0;
+  std::vector<int64_t> level_nb;
+  for (auto &lv : H.levels) {
+    I.level_part0.push_back((int64_t)I.parts.size());
+    level_nb.push_back((int64_t)lv.size());
+    for (auto &P : lv) {
+      PartDesc pd;
+      pd.row_base = rows;
+      pd.start = (int32_t)P.start;
+      pd.n = (int32_t)P.n;
+      I.parts.push_back(pd);
+      if (H.vamana_leaves) rows += P.n;
+    }
+  }
+  I.d_parts.upload(I.parts);
+  v.parts = I.d_parts.p;
+  I.d_level_part0.upload(I.level_part0);
+  I.d_level_nb.upload(level_nb);
+  v.level_part0 = I.d_level_part0.p;
+  v.level_nb = I.d_level_nb.p;
+  if (H.vamana_leaves) {
+    I.d_graph.ensure((size_t)rows * v.rs);
+    // convert + upload partition by partition through a bounded pinned staging buffer
+    const size_t stage_rows = 1 << 20;
+    std::vector<int32_t> stage;
+    size_t pi = 0;
+    for (auto &lv : H.levels)
+      for (auto &P : lv) {
+        const PartDesc &pd = I.parts[pi++];
+        if (P.g.n != P.n) throw std::runtime_error("partition graph missing");
+        for (int64_t r0 = 0; r0 < P.n; r0 += (int64_t)stage_rows) {
+          int64_t cnt = std::min<int64_t>((int64_t)stage_rows, P.n - r0);
+          stage.resize((size_t)cnt * v.rs);
+          for (int64_t i = 0; i < cnt; i++) {
+            const int32_t *r = P.g.row(r0 + i);
+            int32_t *o = stage.data() + i * v.rs;
+            const int deg = r[0];
+            if (deg < 0 || deg > P.g.maxdeg || deg > v.rs) throw std::runtime_error("graph row degree out of range");
+            for (int j = 0; j < deg; j++) {
+              if (r[1 + j] < 0 || r[1 + j] >= P.n) throw std::runtime_error("graph edge out of range");
+              o[j] = r[1 + j];
+            }
+            for (int j = deg; j < v.rs; j++) o[j] = -1;
+          }
+          HIP_CHECK(hipMemcpy(I.d_graph.p + (pd.row_base + r0) * v.rs, stage.data(), stage.size() * 4, hipMemcpyHostToDevice));
+        }
+      }
+    v.graph = I.d_graph.p;
+  }
+  if (!H.offsets.empty()) {
+    std::vector<int64_t> flat, ptr;
+    for (auto &o : H.offsets) {
+      ptr.push_back((int64_t)flat.size());
+      flat.insert(flat.end(), o.begin(), o.end());
+    }
+    ptr.push_back((int64_t)flat.size());
+    I.d_wst_off.upload(flat);
+    I.d_wst_ptr.upload(ptr);
+    v.wst_off = I.d_wst_off.p;
+    v.wst_ptr = I.d_wst_ptr.p;
+  }
+  if (!H.sup_size.empty()) {
+    I.d_sup_size.upload(H.sup_size);
+    I.d_sup_shift.upload(H.sup_shift);
+    v.sup_size = I.d_sup_size.p;
+    v.sup_shift = I.d_sup_shift.p;
+  }
+  I.device_bytes = (int64_t)(I.d_points.bytes() + I.d_labels.bytes() + I.d_decoding.bytes() + I.d_graph.bytes() +
+                             I.d_parts.bytes() + I.d_fv.bytes() + I.d_fi.bytes() + I.d_wst_off.bytes());
+}
+
+struct RoundCfg {
+  LaunchCfg lc;
+  int bits;
+  int slots;
+};
+
+RoundCfg config_for(const wann_index &I, int64_t beam, int64_t work_items) {
+  RoundCfg rc;
+  rc.bits = hash_bits(beam);
+  rc.lc.lds_table = rc.bits <= kMaxLdsBits;
+  rc.lc.lds_beam = beam <= kMaxLdsBeam;
+  const int per_wave = search_lds_bytes_per_wave((int)beam, rc.bits, I.view.stride, rc.lc.lds_table, rc.lc.lds_beam);
+  const int per_block = per_wave * kWavesPerBlock;
+  if (per_block > 160 * 1024) throw std::runtime_error("beam-search LDS footprint exceeds 160 KiB");
+  int blocks_per_cu = std::min(4, (160 * 1024) / per_block);  // <= 16 waves per CU (register budget)
+  blocks_per_cu = std::max(1, blocks_per_cu);
+  int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
+  if (!rc.lc.lds_table) {  // bound the global seen-filter scratch to ~8 GiB
+    int64_t per_slot = (int64_t)4 << rc.bits;
+    int64_t max_slots = std::max<int64_t>(kWavesPerBlock, ((int64_t)8 << 30) / per_slot);
+    blocks = std::min(blocks, max_slots / kWavesPerBlock);
+  }
+  blocks = std::min<int64_t>(blocks, (work_items + kWavesPerBlock - 1) / kWavesPerBlock);
+  rc.lc.blocks = (int)std::max<int64_t>(blocks, 1);
+  rc.slots = rc.lc.blocks * kWavesPerBlock;
+  return rc;
+}
+
+int method_code(const char *m) {
+  if (m && !strcmp(m, "optimized_postfilter")) return M_OPTIMIZED;
+  if (m && !strcmp(m, "three_split")) return M_THREE_SPLIT;
+  return M_FENWICK;  // range_filter_tree.h:76-82: everything else falls through to fenwick
+}
+
+void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int64_t nq, int64_t qid_base,
+               const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st) {
+  if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
+  if (qp.beam_width <= 0) throw std::runtime_error("beam_width must be positive");
+  if (qp.postfiltering_max_beam > (1 << 20)) throw std::runtime_error("postfiltering_max_beam too large");
+  HIP_CHECK(hipSetDevice(I.device));
+  Workspace &W = I.ws;
+  const int k = (int)qp.k;
+  W.ensure(nq, k);
+  I.last = wann_counters{};
+  if (nq == 0) return;
+  HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
+  HIP_CHECK(hipMemsetAsync(W.ctr.p, 0, sizeof(Counters), st));
+  HIP_CHECK(hipEventRecord(W.ev[0], st));
+
+  RouteArgs ra{};
+  ra.ix = I.view;
+  ra.ranges = d_ranges;
+  ra.nq = nq;
+  ra.method = method_code(method);
+  ra.k = k;
+  ra.beam = (int32_t)std::min<int64_t>(qp.beam_width, INT32_MAX);
+  ra.max_beam = (int32_t)std::min<int64_t>(qp.postfiltering_max_beam, INT32_MAX);
+  ra.has_ratio = qp.has_min_query_to_bucket_ratio;
+  ra.ratio = qp.min_query_to_bucket_ratio;
+  ra.tasks = W.tasks.p;
+  ra.graph_list = W.list_a.p;
+  ra.graph_count = W.ints.p + I_GRAPH_COUNT;
+  ra.brute_list = W.list_brute.p;
+  ra.brute_count = W.ints.p + I_BRUTE_COUNT;
+  ra.ctr = W.ctr.p;
+  if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
+
+  const bool may_brute = I.H.spec.kind != WANN_KIND_POSTFILTER && I.H.spec.kind != WANN_KIND_SUPER;
+  if (may_brute) {
+    BruteArgs ba{};
+    ba.ix = I.view;
+    ba.queries = d_queries;
+    ba.tasks = W.tasks.p;
+    ba.list = W.list_brute.p;
+    ba.list_count = W.ints.p + I_BRUTE_COUNT;
+    ba.cursor = W.ints.p + I_BRUTE_CURSOR;
+    ba.k = k;
+    ba.out_key = W.out_key.p;
+    ba.out_cnt = W.out_cnt.p;
+    ba.ctr = W.ctr.p;
+    int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * 4, (nq + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (launch_brute(ba, blocks, st)) throw HipError(std::string("k_brute: ") + launch_last_error());
+  }
+
+  int rounds = 0, nev = 2;
+  std::vector<std::pair<int, int>> timed;  // event index pairs around search launches
+  if (I.H.vamana_leaves && qp.beam_width < qp.postfiltering_max_beam) {
+    int64_t b = qp.beam_width;
+    int32_t *cur_list = W.list_a.p, *nxt_list = W.list_b.p;
+    int32_t *cur_count = W.ints.p + I_GRAPH_COUNT;
+    int64_t work = nq;
+    for (int r = 0; r < kMaxRounds; r++) {
+      const int64_t fb = std::min<int64_t>(b * qp.final_beam_multiply, qp.postfiltering_max_beam);
+      SearchArgs sa{};
+      sa.ix = I.view;
+      sa.queries = d_queries;
+      sa.qid_base = qid_base;
+      sa.tasks = W.tasks.p;
+      sa.list = cur_list;
+      sa.list_count = cur_count;
+      sa.cursor = W.ints.p + I_CURSOR0 + 2 * r;
+      sa.B = (int32_t)b;
+      sa.k = k;
+      sa.limit = qp.limit;
+      sa.degree_limit = (int32_t)std::min<int64_t>(qp.degree_limit, INT32_MAX);
+      sa.is_final = 0;
+      sa.can_double = (2 * b < qp.postfiltering_max_beam) ? 1 : 0;
+      sa.wants_final = (fb > b) ? 1 : 0;
+      sa.next_list = nxt_list;
+      sa.next_count = W.ints.p + I_NEXT0 + r;
+      sa.final_list = W.list_final.p;
+      sa.final_count = W.ints.p + I_FINAL0 + r;
+      sa.out_key = W.out_key.p;
+      sa.out_cnt = W.out_cnt.p;
+      sa.ctr = W.ctr.p;
+      auto launch = [&](SearchArgs &a, int64_t beam, int64_t items) {
+        RoundCfg rc = config_for(I, beam, items);
+        a.bits = rc.bits;
+        a.B = (int32_t)beam;
+        if (!rc.lc.lds_table) {
+          W.g_table.ensure((size_t)rc.slots << rc.bits);
+          a.g_table = W.g_table.p;
+        }
+        if (!rc.lc.lds_beam) {
+          a.g_beam_cap = (beam + 1) & ~(int64_t)1;
+          W.g_beam.ensure((size_t)rc.slots * a.g_beam_cap);
+          a.g_beam = W.g_beam.p;
+        }
+        HIP_CHECK(hipEventRecord(W.ev[nev], st));
+        if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
+        HIP_CHECK(hipEventRecord(W.ev[nev + 1], st));
+        timed.emplace_back(nev, nev + 1);
+        nev += 2;
+        rounds++;
+      };
+      launch(sa, b, work);
+      HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      const int next_n = W.h_ints[I_NEXT0 + r], final_n = W.h_ints[I_FINAL0 + r];
+      if (sa.wants_final && final_n > 0) {
+        SearchArgs fa = sa;
+        fa.list = W.list_final.p;
+        fa.list_count = W.ints.p + I_FINAL0 + r;
+        fa.cursor = W.ints.p + I_CURSOR0 + 2 * r + 1;
+        fa.is_final = 1;
+        launch(fa, fb, final_n);
+      }
+      if (!sa.can_double || next_n == 0) break;
+      b *= 2;
+      std::swap(cur_list, nxt_list);
+      cur_count = W.ints.p + I_NEXT0 + r;
+      work = next_n;
+    }
+  }
+
+  FinalizeArgs fa{};
+  fa.ix = I.view;
+  fa.tasks = W.tasks.p;
+  fa.out_key = W.out_key.p;
+  fa.out_cnt = W.out_cnt.p;
+  fa.nq = nq;
+  fa.k = k;
+  fa.decode = I.H.sorted ? 1 : 0;
+  // padding ids: tree classes 0 (range_filter_tree.h:90), stand-alone post filter -1
+  // (postfilter_vamana.h:212); PrefilterIndex reads past its result there (UB) -> defined as -1
+  fa.pad_id = I.H.sorted ? 0u : 0xFFFFFFFFu;
+  fa.ids = d_ids;
+  fa.dists = d_dists;
+  if (launch_finalize(fa, st)) throw HipError(std::string("k_finalize: ") + launch_last_error());
+  HIP_CHECK(hipMemcpyAsync(W.h_ctr, W.ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipEventRecord(W.ev[1], st));
+  HIP_CHECK(hipStreamSynchronize(st));
+
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, W.ev[0], W.ev[1]));
+  I.last.device_ms = ms;
+  double sk = 0;
+  for (auto &pr : timed) {
+    float t = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t, W.ev[pr.first], W.ev[pr.second]));
+    sk += t;
+  }
+  I.last.search_kernel_ms = sk;
+  I.last.beam_searches = (int64_t)W.h_ctr->beam_searches;
+  I.last.hops = (int64_t)W.h_ctr->hops;
+  I.last.dist_cmps = (int64_t)W.h_ctr->dist_cmps;
+  I.last.brute_rows = (int64_t)W.h_ctr->brute_rows;
+  I.last.label_reads = (int64_t)W.h_ctr->label_reads;
+  I.last.rounds = rounds;
+  if (W.h_ctr->unsupported)
+    throw std::runtime_error("query_method needs the multi-bucket fenwick / three_split cover for " +
+                             std::to_string((long long)W.h_ctr->unsupported) +
+                             " queries; not implemented on the device yet");
+}
+
+BuildSpec make_spec(int kind, int metric, int64_t n, int64_t d, int32_t cutoff, double split_factor,
+                    double shift_factor, const wann_build_params *bp, int threads) {
+  BuildSpec s;
+  s.kind = kind;
+  s.metric = metric;
+  s.n = n;
+  s.d = d;
+  s.cutoff = cutoff;
+  s.split_factor = split_factor;
+  s.shift_factor = shift_factor;
+  s.R = bp ? bp->max_degree : 64;
+  s.L = bp ? bp->limit : 500;
+  s.alpha = bp ? bp->alpha : 1.175;
+  s.cache = (bp && bp->cache_path) ? bp->cache_path : "";
+  s.threads = threads;
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wann_abi_version(void) { return WANN_ABI_VERSION; }
+const char *wann_last_error(void) { return g_err.c_str(); }
+int wann_device_count(void) { return usable_devices(); }
+
+wann_index *wann_index_create(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
+                              const float *labels, int32_t cutoff, double split_factor, double shift_factor,
+                              const wann_build_params *bp, int device, int build_threads) {
+  if (dtype != WANN_DTYPE_F32) {
+    fail(WANN_ERR_UNSUPPORTED, "only float32 points are supported on the device path");
+    return nullptr;
+  }
+  if (kind < 0 || kind > 4 || (metric != 0 && metric != 1) || !points || !labels || n <= 0 || d <= 0) {
+    fail(WANN_ERR_INVALID, "invalid argument to wann_index_create");
+    return nullptr;
+  }
+  if (n >= (int64_t)1 << 31) {
+    fail(WANN_ERR_UNSUPPORTED, "point sets of 2^31 or more rows are not supported");
+    return nullptr;
+  }
+  if (usable_devices() <= device || device < 0) {
+    fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
+    return nullptr;
+  }
+  std::unique_ptr<wann_index> I(new wann_index);
+  try {
+    I->device = device;
+    I->H.spec = make_spec(kind, metric, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
+    build_host_index(I->H, (const float *)points, labels);
+    upload_index(*I);
+  } catch (HipError &e) {
+    fail(WANN_ERR_HIP, e.what());
+    return nullptr;
+  } catch (std::exception &e) {
+    fail(WANN_ERR_INVALID, e.what());
+    return nullptr;
+  }
+  return I.release();
+}
+
+void wann_index_destroy(wann_index *index) { delete index; }
+
+int wann_batch_search_device(wann_index *I, const void *d_queries, const float *d_ranges, int64_t nq,
+                             int64_t query_id_base, const char *method, const wann_query_params *qp,
+                             uint32_t *d_ids, float *d_dists, void *hip_stream) {
+  if (!I || !qp || nq < 0) return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_device");
+  std::lock_guard<std::mutex> lk(I->mu);
+  try {
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : I->own_stream;
+    run_batch(*I, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st);
+  } catch (HipError &e) {
+    return fail(WANN_ERR_HIP, e.what());
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
+  return WANN_OK;
+}
+
+int wann_batch_search(wann_index *I, const void *queries, const float *ranges, int64_t nq, const char *method,
+                      const wann_query_params *qp, uint32_t *ids, float *dists) {
+  if (!I || !qp || nq < 0 || (nq > 0 && (!queries || !ranges || !ids || !dists)))
+    return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search");
+  std::lock_guard<std::mutex> lk(I->mu);
+  try {
+    HIP_CHECK(hipSetDevice(I->device));
+    Workspace &W = I->ws;
+    const int64_t d = I->H.spec.d;
+    if (qp->k <= 0 || qp->k > 1024) throw std::runtime_error("k must be in [1, 1024]");
+    W.q_stage.ensure((size_t)nq * d);
+    W.r_stage.ensure((size_t)nq * 2);
+    W.id_stage.ensure((size_t)nq * qp->k);
+    W.dist_stage.ensure((size_t)nq * qp->k);
+    hipStream_t st = I->own_stream;
+    if (nq) {
+      HIP_CHECK(hipMemcpyAsync(W.q_stage.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
+    }
+    run_batch(*I, W.q_stage.p, W.r_stage.p, nq, 0, method, *qp, W.id_stage.p, W.dist_stage.p, st);
+    if (nq) {
+      HIP_CHECK(hipMemcpyAsync(ids, W.id_stage.p, (size_t)nq * qp->k * 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(dists, W.dist_stage.p, (size_t)nq * qp->k * 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+  } catch (HipError &e) {
+    return fail(WANN_ERR_HIP, e.what());
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
+  return WANN_OK;
+}
+
+int wann_get_counters(const wann_index *I, wann_counters *out) {
+  if (!I || !out) return fail(WANN_ERR_INVALID, "null argument");
+  *out = I->last;
+  return WANN_OK;
+}
+
+int64_t wann_num_points(const wann_index *I) { return I ? I->H.spec.n : -1; }
+int64_t wann_dim(const wann_index *I) { return I ? I->H.spec.d : -1; }
+int64_t wann_num_levels(const wann_index *I) { return I ? (int64_t)I->H.levels.size() : -1; }
+int64_t wann_level_size(const wann_index *I, int64_t level) {
+  if (!I || level < 0 || level >= (int64_t)I->H.levels.size()) return -1;
+  return (int64_t)I->H.levels[level].size();
+}
+int wann_partition_range(const wann_index *I, int64_t level, int64_t idx, int64_t *start, int64_t *end) {
+  if (!I || level < 0 || level >= (int64_t)I->H.levels.size() || idx < 0 || idx >= (int64_t)I->H.levels[level].size())
+    return fail(WANN_ERR_INVALID, "partition out of range");
+  const HostPart &P = I->H.levels[level][idx];
+  *start = P.start;
+  *end = P.start + P.n;
+  return WANN_OK;
+}
+int wann_partition_graph(const wann_index *I, int64_t level, int64_t idx, int32_t *rows, int64_t cap_rows) {
+  if (!I || level < 0 || level >= (int64_t)I->H.levels.size() || idx < 0 || idx >= (int64_t)I->H.levels[level].size())
+    return fail(WANN_ERR_INVALID, "partition out of range");
+  const HostPart &P = I->H.levels[level][idx];
+  if (P.g.n != P.n || cap_rows < P.n) return fail(WANN_ERR_INVALID, "no graph / buffer too small");
+  memcpy(rows, P.g.rows.data(), P.g.rows.size() * 4);
+  return WANN_OK;
+}
+int64_t wann_device_bytes(const wann_index *I) { return I ? I->device_bytes : -1; }
+
+int wann_build_cache_shard(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
+                           const float *labels, int32_t cutoff, double split_factor, double shift_factor,
+                           const wann_build_params *bp, int shard, int nshards, int build_threads) {
+  if (dtype != WANN_DTYPE_F32) return fail(WANN_ERR_UNSUPPORTED, "only float32 points are supported");
+  if (!bp || !bp->cache_path || !*bp->cache_path) return fail(WANN_ERR_INVALID, "cache_path required");
+  if (nshards <= 0 || shard < 0 || shard >= nshards) return fail(WANN_ERR_INVALID, "bad shard");
+  try {
+    HostIndex H;
+    H.spec = make_spec(kind, metric, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
+    build_host_index(H, (const float *)points, labels, shard, nshards);
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
+  return WANN_OK;
+}
+
+int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, const int32_t *graph_rows,
+                         int64_t maxdeg, int64_t subset_start, int64_t subset_n, const float *queries, int64_t nq,
+                         const int64_t *query_ids, int64_t beam, int64_t limit, int64_t degree_limit,
+                         int32_t *out_ids, float *out_dists, int32_t *out_sizes, int64_t *out_hops,
+                         int64_t *out_dist_cmps, int device) {
+  if (usable_devices() <= device || device < 0)
+    return fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
+  if (maxdeg > 64) return fail(WANN_ERR_UNSUPPORTED, "max_degree > 64 is not supported");
+  try {
+    HIP_CHECK(hipSetDevice(device));
+    wann_index I;  // scratch object: reuse config_for / buffers
+    I.device = device;
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    I.num_cus = prop.multiProcessorCount;
+    const int64_t stride = ((d * 4 + 63) / 64) * 16;
+    std::vector<float> pts((size_t)n * stride, 0.f);
+    for (int64_t i = 0; i < n; i++) memcpy(pts.data() + i * stride, points + i * d, (size_t)d * 4);
+    const int rs = (int)(((maxdeg + 15) / 16) * 16);
+    HostGraph g;
+    g.n = subset_n;
+    g.maxdeg = (int32_t)maxdeg;
+    g.rows.assign(graph_rows, graph_rows + (size_t)subset_n * (maxdeg + 1));
+    std::vector<int32_t> rows((size_t)subset_n * rs);
+    convert_rows(g, rs, rows.data());
+    DevBuf<float> d_pts, d_q, d_rd;
+    DevBuf<int32_t> d_rows, d_list, d_ints, d_rid, d_rsz;
+    DevBuf<PartDesc> d_parts;
+    DevBuf<Task> d_tasks;
+    DevBuf<long long> d_hops, d_cmps, d_qids;
+    DevBuf<Counters> d_ctr;
+    d_pts.upload(pts);
+    d_rows.upload(rows);
+    std::vector<PartDesc> parts{{0, (int32_t)subset_start, (int32_t)subset_n}};
+    d_parts.upload(parts);
+    std::vector<float> qv(queries, queries + (size_t)nq * d);
+    d_q.upload(qv);
+    std::vector<Task> tasks((size_t)nq);
+    std::vector<int32_t> list((size_t)nq);
+    std::vector<long long> qids((size_t)nq);
+    for (int64_t i = 0; i < nq; i++) {
+      tasks[i] = Task{(int32_t)i, T_GRAPH, 0, 0, 0, 0, 0.f, 0.f};
+      list[i] = (int32_t)i;
+      qids[i] = query_ids ? query_ids[i] : i;
+    }
+    d_tasks.upload(tasks);
+    d_list.upload(list);
+    d_qids.upload(qids);
+    std::vector<int32_t> ints{(int32_t)nq, 0, 0, 0};
+    d_ints.upload(ints);
+    d_rid.ensure((size_t)nq * beam);
+    d_rd.ensure((size_t)nq * beam);
+    d_rsz.ensure(nq);
+    d_hops.ensure(nq);
+    d_cmps.ensure(nq);
+    d_ctr.ensure(1);
+    HIP_CHECK(hipMemset(d_ctr.p, 0, sizeof(Counters)));
+    I.view.points = d_pts.p;
+    I.view.graph = d_rows.p;
+    I.view.parts = d_parts.p;
+    I.view.labels = d_pts.p;  // unused in raw mode
+    I.view.n = n;
+    I.view.d = (int32_t)d;
+    I.view.stride = (int32_t)stride;
+    I.view.rs = rs;
+    I.view.maxdeg = (int32_t)maxdeg;
+    I.view.metric = metric;
+    RoundCfg rc = config_for(I, beam, nq);
+    DevBuf<int32_t> g_table;
+    DevBuf<unsigned long long> g_beam;
+    SearchArgs sa{};
+    sa.ix = I.view;
+    sa.queries = d_q.p;
+    sa.tasks = d_tasks.p;
+    sa.list = d_list.p;
+    sa.list_count = d_ints.p;
+    sa.cursor = d_ints.p + 1;
+    sa.B = (int32_t)beam;
+    sa.bits = rc.bits;
+    sa.k = 1;
+    sa.limit = limit;
+    sa.degree_limit = (int32_t)std::min<int64_t>(degree_limit, INT32_MAX);
+    sa.ctr = d_ctr.p;
+    sa.raw = 1;
+    sa.raw_ids = d_rid.p;
+    sa.raw_dists = d_rd.p;
+    sa.raw_sizes = d_rsz.p;
+    sa.raw_hops = d_hops.p;
+    sa.raw_cmps = d_cmps.p;
+    sa.raw_qids = d_qids.p;
+    if (!rc.lc.lds_table) {
+      g_table.ensure((size_t)rc.slots << rc.bits);
+      sa.g_table = g_table.p;
+    }
+    if (!rc.lc.lds_beam) {
+      sa.g_beam_cap = (beam + 1) & ~(int64_t)1;
+      g_beam.ensure((size_t)rc.slots * sa.g_beam_cap);
+      sa.g_beam = g_beam.p;
+    }
+    const bool dbg = getenv("WANN_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[wann] raw launch: blocks=%d bits=%d lds_table=%d lds_beam=%d B=%d nq=%ld\n", rc.lc.blocks, rc.bits, rc.lc.lds_table, rc.lc.lds_beam, (int)beam, (long)nq);
+    unsigned int *trace = nullptr;
+    if (dbg) {
+      HIP_CHECK(hipHostMalloc((void **)&trace, rc.slots * sizeof(unsigned int)));
+      memset(trace, 0, rc.slots * sizeof(unsigned int));
+      sa.trace = trace;
+    }
+    if (launch_search(sa, rc.lc, nullptr)) throw HipError(std::string("k_search: ") + launch_last_error());
+    if (dbg) {
+      fprintf(stderr, "[wann] launched, polling\n");
+      for (int it = 0; it < 100; it++) {
+        hipError_t q = hipStreamQuery(nullptr);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) throw HipError(std::string("stream query: ") + hipGetErrorString(q));
+        usleep(100000);
+        if (it == 99) {
+          fprintf(stderr, "[wann] kernel did not finish in 10 s; trace:");
+          for (int s = 0; s < rc.slots && s < 16; s++) fprintf(stderr, " %x", trace[s]);
+          fprintf(stderr, "\n");
+          fflush(stderr);
+          _exit(3);
+        }
+      }
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    if (dbg) fprintf(stderr, "[wann] synced\n");
+    HIP_CHECK(hipMemcpy(out_ids, d_rid.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_dists, d_rd.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_sizes, d_rsz.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    std::vector<long long> hh((size_t)nq), cc((size_t)nq);
+    HIP_CHECK(hipMemcpy(hh.data(), d_hops.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(cc.data(), d_cmps.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < nq; i++) {
+      if (out_hops) out_hops[i] = hh[i];
+      if (out_dist_cmps) out_dist_cmps[i] = cc[i];
+    }
+  } catch (HipError &e) {
+    return fail(WANN_ERR_HIP, e.what());
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
+  return WANN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// window_ann_pybind.cpp -- pybind11 shim over the C ABI (include/wann.h) that re-exports the
+// Python surface of the reference's `window_ann` module for the window-search path
+// (python_bindings/python_bindings.cpp:111-157,204-213 of JoshEngels/RangeFilteredANN):
+// same class names, constructor keywords, batch_search signatures and return tuple, so
+// experiments/wrapper.py and run_our_method.py drive this engine unchanged.
+//
+// Everything computes on the GPU through libwann.so; without a gfx950 device constructors raise.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <optional>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/wann.h"
+
+namespace py = pybind11;
+using namespace pybind11::literals;
+
+namespace wannpy {
+
+struct BuildParams {  // python_bindings.cpp:211-213
+  long max_degree, limit;
+  double alpha;
+  std::string cache_path;
+  BuildParams(long R, long L, double a, std::string c) : max_degree(R), limit(L), alpha(a), cache_path(std::move(c)) {}
+};
+
+struct QueryParams {  // python_bindings.cpp:204-209
+  wann_query_params c{};
+  QueryParams(long k, long beam, double cut, long limit, long degree_limit, long final_beam_multiply,
+              long postfiltering_max_beam, std::optional<float> ratio, bool verbose) {
+    c.k = k;
+    c.beam_width = beam;
+    c.cut = cut;
+    c.limit = limit;
+    c.degree_limit = degree_limit;
+    c.final_beam_multiply = final_beam_multiply;
+    c.postfiltering_max_beam = postfiltering_max_beam;
+    c.has_min_query_to_bucket_ratio = ratio.has_value();
+    c.min_query_to_bucket_ratio = ratio.value_or(0.f);
+    c.verbose = verbose;
+  }
+};
+
+static const BuildParams &default_build_params() {  // python_bindings.cpp:88
+  static BuildParams bp(64, 500, 1.175, "index_cache");
+  return bp;
+}
+
+[[noreturn]] static void raise_last(const char *what) {
+  throw std::runtime_error(std::string(what) + ": " + wann_last_error());
+}
+
+using FArray = py::array_t<float, py::array::c_style | py::array::forcecast>;
+using NeighborsAndDistances = std::pair<py::array_t<unsigned int>, py::array_t<float>>;
+
+class Index {
+ public:
+  Index(int kind, int metric, int dtype, py::array points, FArray labels, int32_t cutoff, double split,
+        double shift, const BuildParams &bp)
+      : kind_(kind) {
+    if (dtype != WANN_DTYPE_F32)
+      throw std::runtime_error("uint8/int8 point sets are not implemented on the MI355X path (float only)");
+    FArray pts = FArray::ensure(points);
+    if (!pts) throw std::runtime_error("points must be convertible to a float32 array");
+    if (pts.ndim() != 2) throw std::runtime_error("points numpy array must be 2-dimensional");           // tree_utils.h:46
+    if (labels.ndim() != 1) throw std::runtime_error("filter data numpy array must be 1-dimensional");    // tree_utils.h:53
+    if (labels.shape(0) != pts.shape(0))
+      throw std::runtime_error("filter data numpy array must have the same number of elements as the points array");
+    wann_build_params wb{bp.max_degree, bp.limit, bp.alpha, bp.cache_path.c_str()};
+    const float *pp = pts.data();
+    const float *lp = labels.data();
+    int64_t n = pts.shape(0), d = pts.shape(1);
+    {
+      py::gil_scoped_release nogil;
+      h_ = wann_index_create(kind, metric, dtype, pp, n, d, lp, cutoff, split, shift, &wb, device_from_env(), 0);
+    }
+    if (!h_) raise_last("index construction failed");
+  }
+  ~Index() { wann_index_destroy(h_); }
+  Index(const Index &) = delete;
+  Index &operator=(const Index &) = delete;
+
+  static int device_from_env() {
+    // one process per GPU: LOCAL_RANK selects the device unless WANN_DEVICE overrides it
+    if (const char *e = getenv("WANN_DEVICE")) return atoi(e);
+    int ndev = wann_device_count();
+    if (const char *e = getenv("LOCAL_RANK")) return ndev > 0 ? atoi(e) % ndev : 0;
+    return 0;
+  }
+
+  NeighborsAndDistances search(FArray &queries, py::object filters, uint64_t nq, const std::string &method,
+                               const QueryParams &qp) {
+    FArray fr = FArray::ensure(filters);
+    if (!fr) throw std::runtime_error("filters must be a sequence of (lo, hi) pairs");
+    if (fr.ndim() != 2 || fr.shape(1) != 2 || (uint64_t)fr.shape(0) < nq)
+      throw std::runtime_error("filters must have shape (num_queries, 2)");
+    if (queries.ndim() != 2 || (uint64_t)queries.shape(0) < nq || queries.shape(1) != wann_dim(h_))
+      throw std::runtime_error("queries must have shape (num_queries, dimension)");
+    size_t k = (size_t)qp.c.k;
+    py::array_t<unsigned int> ids({(size_t)nq, k});
+    py::array_t<float> dists({(size_t)nq, k});
+    const float *qptr = queries.data();
+    const float *rptr = fr.data();
+    unsigned int *ip = ids.mutable_data();
+    float *dp = dists.mutable_data();
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = wann_batch_search(h_, qptr, rptr, (int64_t)nq, method.c_str(), &qp.c, ip, dp);
+    }
+    if (rc) raise_last("batch_search failed");
+    return std::make_pair(ids, dists);
+  }
+
+  // device-resident call: every *_ptr is a device address on this index's GPU (e.g. torch .data_ptr())
+  void search_device(uint64_t q_ptr, uint64_t r_ptr, int64_t nq, int64_t query_id_base, const std::string &method,
+                     const QueryParams &qp, uint64_t ids_ptr, uint64_t dists_ptr, uint64_t stream) {
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = wann_batch_search_device(h_, (const void *)q_ptr, (const float *)r_ptr, nq, query_id_base, method.c_str(),
+                                    &qp.c, (uint32_t *)ids_ptr, (float *)dists_ptr, (void *)stream);
+    }
+    if (rc) raise_last("batch_search_device failed");
+  }
+
+  py::dict counters() const {
+    wann_counters c;
+    wann_get_counters(h_, &c);
+    py::dict d;
+    d["beam_searches"] = c.beam_searches;
+    d["hops"] = c.hops;
+    d["dist_cmps"] = c.dist_cmps;
+    d["brute_rows"] = c.brute_rows;
+    d["label_reads"] = c.label_reads;
+    d["rounds"] = c.rounds;
+    d["device_ms"] = c.device_ms;
+    d["search_kernel_ms"] = c.search_kernel_ms;
+    return d;
+  }
+  std::vector<int64_t> levels() const {
+    std::vector<int64_t> v;
+    for (int64_t l = 0; l < wann_num_levels(h_); l++) v.push_back(wann_level_size(h_, l));
+    return v;
+  }
+  std::pair<int64_t, int64_t> partition_range(int64_t level, int64_t idx) const {
+    int64_t s, e;
+    if (wann_partition_range(h_, level, idx, &s, &e)) raise_last("partition_range");
+    return {s, e};
+  }
+  py::array_t<int32_t> partition_graph(int64_t level, int64_t idx, int64_t max_degree) const {
+    auto [s, e] = partition_range(level, idx);
+    py::array_t<int32_t> rows({(size_t)(e - s), (size_t)(max_degree + 1)});
+    if (wann_partition_graph(h_, level, idx, rows.mutable_data(), e - s)) raise_last("partition_graph");
+    return rows;
+  }
+  int64_t device_bytes() const { return wann_device_bytes(h_); }
+  int64_t num_points() const { return wann_num_points(h_); }
+  int64_t dim() const { return wann_dim(h_); }
+
+ private:
+  int kind_;
+  wann_index *h_ = nullptr;
+};
+
+template <int KIND, int METRIC, int DTYPE>
+struct IndexT : Index {
+  using Index::Index;
+};
+
+template <typename C>
+static void common_defs(py::class_<C> &c) {
+  c.def("batch_search_device", &C::search_device, "queries_ptr"_a, "filters_ptr"_a, "num_queries"_a,
+        "query_id_base"_a, "query_method"_a, "query_params"_a, "ids_ptr"_a, "dists_ptr"_a, "stream"_a = 0)
+      .def("counters", &C::counters)
+      .def("levels", &C::levels)
+      .def("partition_range", &C::partition_range)
+      .def("partition_graph", &C::partition_graph, "level"_a, "idx"_a, "max_degree"_a)
+      .def("device_bytes", &C::device_bytes)
+      .def("num_points", &C::num_points)
+      .def("dim", &C::dim);
+}
+
+template <int METRIC, int DTYPE>
+static void add_variant(py::module_ &m, const std::string &agnostic) {
+  {
+    using C = IndexT<WANN_KIND_PREFILTER, METRIC, DTYPE>;
+    py::class_<C> c(m, ("PrefilterIndex" + agnostic).c_str());
+    c.def(py::init([](py::array points, FArray fv, const BuildParams &bp) {
+            return new C(WANN_KIND_PREFILTER, METRIC, DTYPE, points, fv, 1000, 2, 0.5, bp);
+          }),
+          "points"_a, "filter_values"_a, "build_params"_a = default_build_params())
+        .def("batch_search",
+             [](C &self, FArray &q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
+             "queries"_a, "filters"_a, "num_queries"_a, "query_params"_a);
+    common_defs(c);
+  }
+  {
+    using C = IndexT<WANN_KIND_TREE_PREFILTER, METRIC, DTYPE>;
+    py::class_<C> c(m, ("RangeFilterTreeIndex" + agnostic).c_str());
+    c.def(py::init([](py::array points, FArray fv, int32_t cutoff, size_t split, const BuildParams &bp) {
+            return new C(WANN_KIND_TREE_PREFILTER, METRIC, DTYPE, points, fv, cutoff, (double)split, 0.5, bp);
+          }),
+          "points"_a, "filter_values"_a, "cutoff"_a = 1000, "split_factor"_a = 2,
+          "build_params"_a = default_build_params())
+        .def("batch_search",
+             [](C &self, FArray &q, py::object f, uint64_t nq, const std::string &method, const QueryParams &qp) {
+               return self.search(q, f, nq, method, qp);
+             },
+             "queries"_a, "filters"_a, "num_queries"_a, "query_method"_a, "query_params"_a);
+    common_defs(c);
+  }
+  {
+    using C = IndexT<WANN_KIND_POSTFILTER, METRIC, DTYPE>;
+    py::class_<C> c(m, ("PostfilterVamanaIndex" + agnostic).c_str());
+    c.def(py::init([](py::array points, FArray fv, const BuildParams &bp) {
+            return new C(WANN_KIND_POSTFILTER, METRIC, DTYPE, points, fv, 1000, 2, 0.5, bp);
+          }),
+          "points"_a, "filters"_a, "build_params"_a = default_build_params())
+        .def("batch_search",
+             [](C &self, FArray &q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
+             "queries"_a, "filters"_a, "num_queries"_a, "query_params"_a);
+    common_defs(c);
+  }
+  {
+    using C = IndexT<WANN_KIND_TREE_VAMANA, METRIC, DTYPE>;
+    py::class_<C> c(m, ("VamanaRangeFilterTreeIndex" + agnostic).c_str());
+    c.def(py::init([](py::array points, FArray fv, int32_t cutoff, size_t split, const BuildParams &bp) {
+            return new C(WANN_KIND_TREE_VAMANA, METRIC, DTYPE, points, fv, cutoff, (double)split, 0.5, bp);
+          }),
+          "points"_a, "filter_values"_a, "cutoff"_a = 1000, "split_factor"_a = 2,
+          "build_params"_a = default_build_params())
+        .def("batch_search",
+             [](C &self, FArray &q, py::object f, uint64_t nq, const std::string &method, const QueryParams &qp) {
+               return self.search(q, f, nq, method, qp);
+             },
+             "queries"_a, "filters"_a, "num_queries"_a, "query_method"_a, "query_params"_a);
+    common_defs(c);
+  }
+  {
+    using C = IndexT<WANN_KIND_SUPER, METRIC, DTYPE>;
+    py::class_<C> c(m, ("SuperOptimizedPostfilterTreeIndex" + agnostic).c_str());
+    c.def(py::init([](py::array points, FArray fv, int32_t cutoff, float split, float shift, const BuildParams &bp) {
+            return new C(WANN_KIND_SUPER, METRIC, DTYPE, points, fv, cutoff, (double)split, (double)shift, bp);
+          }),
+          "points"_a, "filter_values"_a, "cutoff"_a = 1000, "split_factor"_a = 2, "shift_factor"_a = 0.5,
+          "build_params"_a = default_build_params())
+        .def("batch_search",
+             [](C &self, FArray &q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
+             "queries"_a, "filters"_a, "num_queries"_a, "query_params"_a);
+    common_defs(c);
+  }
+}
+
+}  // namespace wannpy
+
+PYBIND11_MODULE(_window_ann, m) {
+  using namespace wannpy;
+  m.doc() = "WindowANN Python bindings -- MI355X (gfx950) engine";
+  m.attr("__version__") = "mi355x-dev";
+
+  py::module_ defaults = m.def_submodule("defaults");  // python_bindings.cpp:169-175
+  defaults.attr("METRIC") = "Euclidian";
+  defaults.attr("ALPHA") = 1.2;
+  defaults.attr("GRAPH_DEGREE") = 64;
+  defaults.attr("BEAMWIDTH") = 128;
+
+  py::class_<QueryParams>(m, "QueryParams")
+      .def(py::init<long, long, double, long, long, long, long, std::optional<float>, bool>(), "k"_a, "beam_width"_a,
+           "cut"_a, "limit"_a, "degree_limit"_a, "final_beam_multiply"_a, "postfiltering_max_beam"_a,
+           "min_query_to_bucket_ratio"_a, "verbose"_a);
+  py::class_<BuildParams>(m, "BuildParams")
+      .def(py::init<long, long, double, std::string>(), "max_degree"_a, "limit"_a, "alpha"_a, "cache_path"_a);
+
+  add_variant<WANN_METRIC_L2, WANN_DTYPE_F32>(m, "FloatEuclidian");
+  add_variant<WANN_METRIC_MIPS, WANN_DTYPE_F32>(m, "FloatMips");
+  add_variant<WANN_METRIC_L2, WANN_DTYPE_U8>(m, "UInt8Euclidian");
+  add_variant<WANN_METRIC_MIPS, WANN_DTYPE_U8>(m, "UInt8Mips");
+  add_variant<WANN_METRIC_L2, WANN_DTYPE_I8>(m, "Int8Euclidian");
+  add_variant<WANN_METRIC_MIPS, WANN_DTYPE_I8>(m, "Int8Mips");
+
+  m.def("device_count", [] { return wann_device_count(); });
+  m.def("abi_version", [] { return wann_abi_version(); });
+  m.def(
+      "build_cache_shard",
+      [](int kind, int metric, FArray points, FArray labels, int32_t cutoff, double split, double shift,
+         const BuildParams &bp, int shard, int nshards, int threads) {
+        if (points.ndim() != 2 || labels.ndim() != 1) throw std::runtime_error("bad shapes");
+        wann_build_params wb{bp.max_degree, bp.limit, bp.alpha, bp.cache_path.c_str()};
+        const float *pp = points.data();
+        const float *lp = labels.data();
+        int64_t n = points.shape(0), d = points.shape(1);
+        int rc;
+        {
+          py::gil_scoped_release nogil;
+          rc = wann_build_cache_shard(kind, metric, WANN_DTYPE_F32, pp, n, d, lp, cutoff, split, shift, &wb, shard,
+                                      nshards, threads);
+        }
+        if (rc) raise_last("build_cache_shard failed");
+      },
+      "kind"_a, "metric"_a, "points"_a, "filter_values"_a, "cutoff"_a, "split_factor"_a, "shift_factor"_a,
+      "build_params"_a, "shard"_a, "nshards"_a, "threads"_a = 0);
+  m.def(
+      "raw_beam_search",
+      [](int metric, FArray points, py::array_t<int32_t, py::array::c_style | py::array::forcecast> graph_rows,
+         int64_t subset_start, FArray queries, py::array_t<int64_t, py::array::c_style | py::array::forcecast> query_ids,
+         int64_t beam, int64_t limit, int64_t degree_limit, int device) {
+        if (points.ndim() != 2 || graph_rows.ndim() != 2 || queries.ndim() != 2) throw std::runtime_error("bad shapes");
+        int64_t n = points.shape(0), d = points.shape(1), sn = graph_rows.shape(0), md = graph_rows.shape(1) - 1;
+        int64_t nq = queries.shape(0);
+        py::array_t<int32_t> ids({(size_t)nq, (size_t)beam});
+        py::array_t<float> dists({(size_t)nq, (size_t)beam});
+        py::array_t<int32_t> sizes((size_t)nq);
+        py::array_t<int64_t> hops((size_t)nq), cmps((size_t)nq);
+        int rc = wann_raw_beam_search(metric, points.data(), n, d, graph_rows.data(), md, subset_start, sn,
+                                      queries.data(), nq, query_ids.data(), beam, limit, degree_limit,
+                                      ids.mutable_data(), dists.mutable_data(), sizes.mutable_data(),
+                                      hops.mutable_data(), cmps.mutable_data(), device);
+        if (rc) raise_last("raw_beam_search failed");
+        return py::make_tuple(ids, dists, sizes, hops, cmps);
+      },
+      "metric"_a, "points"_a, "graph_rows"_a, "subset_start"_a, "queries"_a, "query_ids"_a, "beam"_a,
+      "limit"_a = 10000000, "degree_limit"_a = 10000, "device"_a = 0);
+}

@@ -1,0 +1,195 @@
+"""GPU: the HIP path (through the pybind11 shim -> C ABI -> gfx950 kernels) against the oracle on
+the same seeded inputs and against the golden vectors of the real reference.  Integer / index
+results must be bit-exact; float distances are compared bit-exactly too (the kernels reproduce the
+reference's fp32 evaluation order), which is stricter than north_star's 1e-5 relative bound."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from util import distinct_labels, sift_like, unit_mixture, windows
+
+pytestmark = pytest.mark.gpu
+FLT_MAX = np.finfo(np.float32).max
+
+
+def _qp(mod, beam, mult=1, k=10, max_beam=10000, ratio=None):
+    return mod.QueryParams(k, beam, 1.35, 10_000_000, 10_000, mult, max_beam, ratio, False)
+
+
+# ------------------------------------------------------------------------------------------
+# raw kernel: one beam search per query on one graph
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,gen,d", [(0, sift_like, 128), (1, unit_mixture, 100), (0, unit_mixture, 40)])
+@pytest.mark.parametrize("beam", [1, 7, 10, 40, 64, 65, 100, 160, 700, 2500])
+def test_raw_beam_search_matches_oracle(oracle, wa, gpu, metric, gen, d, beam):
+    n, nq, R, L = 3000, 96, 32, 64
+    g = gen(n, d, 11)
+    X, Q = g(n), g(nq)
+    Xp = oracle.pad_rows(X)
+    start, sn = 500, 2000  # a partition in the middle of the point set
+    rows = oracle.vamana_build(Xp, d, metric, start, sn, R, L, 1.0)
+    qids = np.arange(nq, dtype=np.int64)
+    qids[::3] += 700  # some queries carry an id that names a node of the partition (self-skip quirk)
+    ids, dists, sizes, hops, cmps = wa.raw_beam_search(metric, X, rows, start, Q, qids, beam)
+    for i in range(nq):
+        oi, od, vi, vd, dc = oracle.beam_search(rows, Xp, d, metric, start, Q[i], int(qids[i]), beam)
+        m = int(sizes[i])
+        assert m == len(oi), (i, m, len(oi))
+        assert np.array_equal(ids[i, :m], oi), (i, ids[i, :m], oi)
+        assert np.array_equal(dists[i, :m], od), i
+        assert int(hops[i]) == len(vi), (i, hops[i], len(vi))
+        assert int(cmps[i]) == dc, (i, cmps[i], dc)
+
+
+def test_raw_beam_search_limits(oracle, wa, gpu):
+    n, d, nq = 1500, 32, 40
+    g = sift_like(n, d, 5)
+    X, Q = g(n), g(nq)
+    Xp = oracle.pad_rows(X)
+    rows = oracle.vamana_build(Xp, d, 0, 0, n, 24, 48, 1.0)
+    qids = np.arange(nq, dtype=np.int64) + 10**6
+    for limit, dl in [(5, 10000), (10**7, 7), (3, 3)]:
+        ids, dists, sizes, hops, cmps = wa.raw_beam_search(0, X, rows, 0, Q, qids, 20, limit, dl)
+        for i in range(nq):
+            oi, od, vi, vd, dc = oracle.beam_search(rows, Xp, d, 0, 0, Q[i], int(qids[i]), 20, limit=limit, degree_limit=dl)
+            assert np.array_equal(ids[i, :sizes[i]], oi) and np.array_equal(dists[i, :sizes[i]], od)
+            assert int(hops[i]) == len(vi) and int(cmps[i]) == dc
+
+
+# ------------------------------------------------------------------------------------------
+# golden vectors of the real reference, through reference-built graph files
+# ------------------------------------------------------------------------------------------
+SUPPORTED = lambda kind, method: method not in ("fenwick", "three_split")  # noqa: E731
+
+
+@pytest.mark.parametrize("name", list(gu.FIXTURES))
+@pytest.mark.parametrize("kind", list(gu.KINDS))
+def test_golden_reference_outputs(wa, gpu, tmp_path, name, kind):
+    idx, data = gu.build_index(wa, name, kind, tmp_path)
+    K = int(data["meta"][3])
+    Q = data["Q"]
+    nq = Q.shape[0]
+    n = 0
+    for key, method, beam, mult, p in gu.cases(data, kind):
+        if not SUPPORTED(kind, method):
+            continue
+        args = (Q, data["W_" + p], nq) + ((method,) if kind.endswith("RangeFilterTreeIndex") else ())
+        ids, dists = idx.batch_search(*args, _qp(wa, beam, mult, K))
+        tie = kind in gu.TIE_AWARE_KINDS or p in ("-7", "edge")
+        ok, why = gu.same_rows(data["ids|" + key], data["dists|" + key], ids, dists, tie)
+        assert ok, f"{name} {key}: {why}"
+        n += 1
+    assert n > 0
+
+
+@pytest.mark.parametrize("name", list(gu.FIXTURES))
+def test_golden_quirks(wa, gpu, tmp_path, name):
+    idx, data = gu.build_index(wa, name, "VamanaRangeFilterTreeIndex", tmp_path)
+    Q, W = data["Q"], data["W_-3"]
+    nq = Q.shape[0]
+    ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, 64, 1, 10, max_beam=64))
+    assert np.array_equal(ids, data["ids|VamanaRangeFilterTreeIndex|maxbeam"])
+    assert np.array_equal(dists, data["dists|VamanaRangeFilterTreeIndex|maxbeam"])
+    ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, 8, 1, 10, max_beam=20))
+    assert np.array_equal(ids, data["ids|VamanaRangeFilterTreeIndex|overshoot"])
+    assert np.array_equal(dists, data["dists|VamanaRangeFilterTreeIndex|overshoot"])
+
+
+# ------------------------------------------------------------------------------------------
+# product-built indexes against the oracle on larger seeded inputs (graphs shared via the cache)
+# ------------------------------------------------------------------------------------------
+CASES = [
+    ("VamanaRangeFilterTreeIndex", "FloatEuclidian", sift_like, 128, 6000, dict(cutoff=500, split_factor=2)),
+    ("VamanaRangeFilterTreeIndex", "FloatMips", unit_mixture, 100, 5000, dict(cutoff=400, split_factor=3)),
+    ("SuperOptimizedPostfilterTreeIndex", "FloatMips", unit_mixture, 100, 5000, dict(cutoff=400, split_factor=2, shift_factor=0.5)),
+    ("SuperOptimizedPostfilterTreeIndex", "FloatEuclidian", sift_like, 96, 5000, dict(cutoff=300, split_factor=2.5, shift_factor=0.3)),
+    ("PostfilterVamanaIndex", "FloatEuclidian", sift_like, 64, 4000, dict()),
+    ("RangeFilterTreeIndex", "FloatEuclidian", sift_like, 48, 4000, dict(cutoff=300, split_factor=2)),
+    ("PrefilterIndex", "FloatMips", unit_mixture, 100, 4000, dict()),
+]
+
+
+@pytest.mark.parametrize("kind,sfx,gen,d,n,kw", CASES)
+def test_index_matches_oracle(oracle, wa, gpu, tmp_path, kind, sfx, gen, d, n, kw):
+    nq = 300
+    g = gen(n, d, 21)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 3)
+    cache = str(tmp_path) + "/"
+    labkw = "filters" if kind == "PostfilterVamanaIndex" else "filter_values"
+    pi = getattr(wa, kind + sfx)(X, **{labkw: labels}, build_params=wa.BuildParams(32, 64, 1.0, cache), **kw)
+    oi = getattr(oracle, kind + sfx)(X, **{labkw: labels}, build_params=oracle.BuildParams(32, 64, 1.0, cache), **kw)
+    tree = kind.endswith("RangeFilterTreeIndex")
+    fractions = [-9, -6, -4, -2, -1, 0] if kind != "PrefilterIndex" else [-6, -3, -1]
+    for p in fractions:
+        W = windows(labels, nq, p, seed=50 + p)
+        for beam, mult in [(10, 1), (20, 3), (80, 1), (200, 2)]:
+            a = (Q, W, nq) + (("optimized_postfilter",) if tree else ())
+            ids, dists = pi.batch_search(*a, _qp(wa, beam, mult))
+            eids, edists = oi.batch_search(*a, _qp(oracle, beam, mult))
+            tie = kind in gu.TIE_AWARE_KINDS or p <= -6
+            ok, why = gu.same_rows(eids, edists, ids, dists, tie)
+            assert ok, f"{kind}{sfx} p={p} beam={beam} mult={mult}: {why}"
+            c, oc = pi.counters(), oi.last_counters
+            assert c["beam_searches"] == oc["searches"] and c["hops"] == oc["hops"]
+            assert c["dist_cmps"] + c["brute_rows"] == oc["dist_cmps"]
+
+
+def test_edge_cases(oracle, wa, gpu, tmp_path):
+    n, d, nq = 3000, 32, 64
+    g = sift_like(n, d, 9)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 4)
+    cache = str(tmp_path) + "/"
+    pi = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=400, split_factor=2, build_params=wa.BuildParams(24, 48, 1.0, cache))
+    oi = oracle.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=400, split_factor=2, build_params=oracle.BuildParams(24, 48, 1.0, cache))
+    s = np.sort(labels)
+    W = np.zeros((nq, 2))
+    W[0::4] = (5.0, 6.0)                 # outside the label span -> padding
+    W[1::4] = (s[10], s[10])             # zero width -> empty index range
+    W[2::4] = (s[100], s[103])           # fewer than k points -> padded tail
+    W[3::4] = (s[0] - 1, s[-1] + 1)      # everything
+    for beam, mult, mb in [(10, 1, 10000), (16, 2, 10000), (16, 1, 40), (50, 4, 120)]:
+        ids, dists = pi.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult, 10, mb))
+        eids, edists = oi.batch_search(Q, W, nq, "optimized_postfilter", _qp(oracle, beam, mult, 10, mb))
+        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        assert ok, why
+    assert (ids[0] == 0).all() and (dists[0] == FLT_MAX).all()
+    # empty batch and k = 1 / k = 37
+    ids, dists = pi.batch_search(Q[:0], W[:0], 0, "optimized_postfilter", _qp(wa, 10))
+    assert ids.shape == (0, 10)
+    for k in (1, 37):
+        ids, dists = pi.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, 40, 1, k))
+        eids, edists = oi.batch_search(Q, W, nq, "optimized_postfilter", _qp(oracle, 40, 1, k))
+        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        assert ok, why
+    # errors: bad shapes raise RuntimeError like the reference (tree_utils.h:46-60)
+    with pytest.raises(RuntimeError):
+        wa.VamanaRangeFilterTreeIndexFloatEuclidian(X.reshape(-1), labels)
+    with pytest.raises(RuntimeError):
+        wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels[:-1])
+
+
+def test_device_resident_call_matches_host_call(wa, gpu, tmp_path):
+    torch = pytest.importorskip("torch")
+    n, d, nq = 4000, 64, 500
+    g = sift_like(n, d, 2)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 5)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=500, split_factor=2, build_params=wa.BuildParams(32, 64, 1.0, ""))
+    W = windows(labels, nq, -3, 1).astype(np.float32)
+    qp = _qp(wa, 20, 2)
+    ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", qp)
+    dev = torch.device("cuda:0")
+    tq, tw = torch.from_numpy(Q).to(dev), torch.from_numpy(W).to(dev)
+    tids = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+    tdist = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    idx.batch_search_device(tq.data_ptr(), tw.data_ptr(), nq, 0, "optimized_postfilter", qp, tids.data_ptr(), tdist.data_ptr(), 0)
+    assert np.array_equal(tids.cpu().numpy().view(np.uint32), ids)
+    assert np.array_equal(tdist.cpu().numpy(), dists)
+    # a shard keeps its global query numbering (query row number = "own id" quirk)
+    half = nq // 2
+    idx.batch_search_device(tq[half:].data_ptr(), tw[half:].data_ptr(), nq - half, half, "optimized_postfilter", qp,
+                            tids[half:].data_ptr(), tdist[half:].data_ptr(), 0)
+    assert np.array_equal(tids.cpu().numpy().view(np.uint32), ids)

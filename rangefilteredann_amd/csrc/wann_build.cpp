@@ -23,6 +23,7 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+#include <chrono>
 
 namespace wann {
 
@@ -305,12 +306,20 @@ void build_search(const BuildView &V, const HostGraph &G, int32_t index, Scratch
     const int64_t deg = std::min<int64_t>(row[0], G.maxdeg);
     const float cutoff = ((int64_t)S.front.size() < B) ? (float)INT_MAX : key_dist(S.front.back());
     S.cand.clear();
+    int32_t kept[64 + 1];
+    int nk = 0;
     for (int64_t i = 0; i < deg; i++) {
       const int32_t a = row[1 + i];
       if ((int64_t)a == qid) continue;
       const uint64_t loc = mix64((uint64_t)(int64_t)a) & mask;
       if (S.table[loc] == a) continue;
       S.table[loc] = a;
+      kept[nk++] = a;
+      const char *pv = (const char *)V.vec(a);  // the search is latency bound: get the misses in flight
+      for (int64_t off = 0; off < V.d * 4; off += 64) __builtin_prefetch(pv + off);
+    }
+    for (int i = 0; i < nk; i++) {
+      const int32_t a = kept[i];
       const float dd = host_distance(V.metric, V.vec(a), q, (int)V.d);
       if (dd >= cutoff) continue;
       S.cand.push_back(mkkey(dd, a));
@@ -353,6 +362,8 @@ void build_search(const BuildView &V, const HostGraph &G, int32_t index, Scratch
     for (size_t x = sp; x < S.front.size(); x++)
       if (!(S.front[x] & 1)) {
         p = x;
+        const char *pr = (const char *)G.row(key_id(S.front[x]));
+        for (int off = 0; off < (G.maxdeg + 1) * 4; off += 64) __builtin_prefetch(pr + off);
         break;
       }
   }
@@ -388,106 +399,168 @@ void robust_prune(const BuildView &V, const HostGraph &G, int32_t p, std::vector
 
 }  // namespace
 
-void vamana_build(const float *pts, int64_t stride, int64_t d, int metric, int64_t start, int64_t n,
-                  int64_t R, int64_t L, double alpha, HostGraph &G, int threads) {
-  BuildView V{pts, stride, d, metric, start, n, R, L, alpha};
-  G.n = n;
-  G.maxdeg = (int32_t)R;
-  G.rows.assign((size_t)n * (R + 1), 0);
-  if (n == 0) return;
-  std::vector<int32_t> order((size_t)n);
-  for (int64_t i = 0; i < n; i++) order[i] = (int32_t)i;
-  std::sort(order.begin(), order.end(), [](int32_t a, int32_t b) { return mix64((uint64_t)a) < mix64((uint64_t)b); });
-  size_t cap = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);  // vamana/index.h:224-226
-  if (cap == 0) cap = (size_t)n;
-  const size_t m = (size_t)n;
-  size_t count = 0, inc = 0;
+// Lock-step build of many partitions: round r inserts batch r of EVERY unfinished partition, so one
+// parallel region covers ~2 % of all points of all partitions (hundreds of thousands of searches
+// at SIFT-1M scale) instead of one partition's batch.  Each partition sees exactly the batch
+// schedule of a stand-alone build, so the graphs do not depend on how partitions are grouped or
+// on the thread count.
+namespace {
+struct Job {
+  BuildView V;
+  HostGraph *G;
+  std::vector<int32_t> order;
+  size_t cap = 0, count = 0, inc = 0, lo = 0, hi = 0;
+  bool active = true;
+  std::vector<std::vector<int32_t>> fresh;
+  std::vector<std::pair<int32_t, int32_t>> rev;
+  std::vector<size_t> cuts;
+};
+}  // namespace
+
+static void build_many(std::vector<Job> &jobs, int threads) {
   const int nthr = std::max(1, threads);
+  parallel_for((int64_t)jobs.size(), nthr, [&](int64_t j) {
+    Job &J = jobs[j];
+    const int64_t n = J.V.n;
+    J.G->n = n;
+    J.G->maxdeg = (int32_t)J.V.R;
+    J.G->rows.assign((size_t)n * (J.V.R + 1), 0);
+    J.order.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) J.order[i] = (int32_t)i;
+    std::sort(J.order.begin(), J.order.end(), [](int32_t a, int32_t b) { return mix64((uint64_t)a) < mix64((uint64_t)b); });
+    J.cap = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);  // vamana/index.h:224-226
+    if (J.cap == 0) J.cap = (size_t)n;
+    J.active = n > 0;
+  });
   static thread_local Scratch tls_scratch;  // one per pool thread, reused across builds
-  while (count < m) {
-    size_t lo, hi;
-    if (std::pow(2.0, (double)inc) <= (double)cap) {
-      lo = (size_t)std::pow(2.0, (double)inc) - 1;
-      hi = std::min((size_t)std::pow(2.0, (double)(inc + 1)), m) - 1;
-      count = hi;
-    } else {
-      lo = count;
-      hi = std::min(count + cap, m);
-      count += cap;
+  std::vector<std::pair<int32_t, int32_t>> items;  // (job, index in batch) / (job, group)
+  const bool verbose = getenv("WANN_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tA = 0, tB = 0, tC = 0, t0 = now();
+  size_t round_no = 0, total_items = 0;
+  for (;;) {
+    items.clear();
+    for (size_t j = 0; j < jobs.size(); j++) {
+      Job &J = jobs[j];
+      if (!J.active) continue;
+      const size_t m = (size_t)J.V.n;
+      if (std::pow(2.0, (double)J.inc) <= (double)J.cap) {  // vamana/index.h:245-253
+        J.lo = (size_t)std::pow(2.0, (double)J.inc) - 1;
+        J.hi = std::min((size_t)std::pow(2.0, (double)(J.inc + 1)), m) - 1;
+        J.count = J.hi;
+      } else {
+        J.lo = J.count;
+        J.hi = std::min(J.count + J.cap, m);
+        J.count += J.cap;
+      }
+      J.fresh.assign(J.hi - J.lo, {});
+      for (size_t bi = 0; bi < J.hi - J.lo; bi++) items.emplace_back((int32_t)j, (int32_t)bi);
     }
-    const size_t bs = hi - lo;
-    std::vector<std::vector<int32_t>> fresh(bs);
-    parallel_for((int64_t)bs, nthr, [&](int64_t bi) {
+    if (items.empty()) break;
+    round_no++;
+    total_items += items.size();
+    double t1 = now();
+    // phase A: search the snapshot + robustPrune, every insert of every partition's batch
+    parallel_for((int64_t)items.size(), nthr, [&](int64_t it) {
+      Job &J = jobs[items[it].first];
+      const int32_t index = J.order[J.lo + items[it].second];
       Scratch &S = tls_scratch;
-      const int32_t index = order[lo + bi];
-      build_search(V, G, index, S);
+      build_search(J.V, *J.G, index, S);
       std::vector<uint64_t> cand(S.visited);
-      robust_prune(V, G, index, cand, true, fresh[bi]);
+      robust_prune(J.V, *J.G, index, cand, true, J.fresh[items[it].second]);
     });
-    for (size_t bi = 0; bi < bs; bi++) {
-      int32_t *row = G.row(order[lo + bi]);
-      row[0] = (int32_t)fresh[bi].size();
-      std::copy(fresh[bi].begin(), fresh[bi].end(), row + 1);
-    }
-    // reverse edges grouped by target, sources in batch order (vamana/index.h:277-306)
-    std::vector<std::pair<int32_t, int32_t>> rev;
-    for (size_t bi = 0; bi < bs; bi++)
-      for (int32_t t : fresh[bi]) rev.emplace_back(t, order[lo + bi]);
-    std::stable_sort(rev.begin(), rev.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-    std::vector<size_t> cuts;
-    for (size_t i = 0; i < rev.size(); i++)
-      if (i == 0 || rev[i].first != rev[i - 1].first) cuts.push_back(i);
-    cuts.push_back(rev.size());
-    parallel_for((int64_t)cuts.size() - 1, nthr, [&](int64_t gi) {
-      const size_t b = cuts[gi], e = cuts[gi + 1];
-      const int32_t tgt = rev[b].first;
-      int32_t *row = G.row(tgt);
-      if ((int64_t)(e - b) + row[0] <= R) {
-        for (size_t i = b; i < e; i++) row[1 + row[0]++] = rev[i].second;
+    double t2 = now();
+    tA += t2 - t1;
+    // phase B: publish the batch's out-edges, group the reverse edges by target in batch order
+    parallel_for((int64_t)jobs.size(), nthr, [&](int64_t j) {
+      Job &J = jobs[j];
+      if (!J.active) return;
+      const size_t bs = J.hi - J.lo;
+      for (size_t bi = 0; bi < bs; bi++) {
+        int32_t *row = J.G->row(J.order[J.lo + bi]);
+        row[0] = (int32_t)J.fresh[bi].size();
+        std::copy(J.fresh[bi].begin(), J.fresh[bi].end(), row + 1);
+      }
+      J.rev.clear();
+      for (size_t bi = 0; bi < bs; bi++)
+        for (int32_t t : J.fresh[bi]) J.rev.emplace_back(t, J.order[J.lo + bi]);
+      std::stable_sort(J.rev.begin(), J.rev.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+      J.cuts.clear();
+      for (size_t i = 0; i < J.rev.size(); i++)
+        if (i == 0 || J.rev[i].first != J.rev[i - 1].first) J.cuts.push_back(i);
+      J.cuts.push_back(J.rev.size());
+    });
+    double t3 = now();
+    tB += t3 - t2;
+    // phase C: reverse edges -- append when the row has room, else robustPrune (vamana/index.h:297-306)
+    items.clear();
+    for (size_t j = 0; j < jobs.size(); j++)
+      if (jobs[j].active)
+        for (size_t g = 0; g + 1 < jobs[j].cuts.size(); g++) items.emplace_back((int32_t)j, (int32_t)g);
+    parallel_for((int64_t)items.size(), nthr, [&](int64_t it) {
+      Job &J = jobs[items[it].first];
+      const size_t b = J.cuts[items[it].second], e = J.cuts[items[it].second + 1];
+      const int32_t tgt = J.rev[b].first;
+      int32_t *row = J.G->row(tgt);
+      if ((int64_t)(e - b) + row[0] <= J.V.R) {
+        for (size_t i = b; i < e; i++) row[1 + row[0]++] = J.rev[i].second;
       } else {
         std::vector<uint64_t> cand;
         cand.reserve(e - b + row[0]);
-        for (size_t i = b; i < e; i++) cand.push_back(mkkey(V.dist(rev[i].second, tgt), rev[i].second));
+        for (size_t i = b; i < e; i++) cand.push_back(mkkey(J.V.dist(J.rev[i].second, tgt), J.rev[i].second));
         std::vector<int32_t> out;
-        robust_prune(V, G, tgt, cand, true, out);
+        robust_prune(J.V, *J.G, tgt, cand, true, out);
         row[0] = (int32_t)out.size();
         std::copy(out.begin(), out.end(), row + 1);
       }
     });
-    inc++;
+    tC += now() - t3;
+    if (verbose && (round_no % 10 == 0))
+      fprintf(stderr, "[wann build] round %zu: %zu inserts so far, search+prune %.1fs, group %.1fs, reverse %.1fs\n", round_no,
+              total_items, tA, tB, tC);
+    for (auto &J : jobs) {
+      if (!J.active) continue;
+      J.inc++;
+      if (J.count >= (size_t)J.V.n) {
+        J.active = false;
+        J.fresh.clear();
+        J.fresh.shrink_to_fit();
+        J.rev.clear();
+        J.rev.shrink_to_fit();
+      }
+    }
   }
-  parallel_for(n, nthr, [&](int64_t i) {  // final neighbour sort (vamana/index.h:131-134)
-    int32_t *row = G.row(i);
+  if (verbose)
+    fprintf(stderr, "[wann build] %zu partitions, %zu inserts, %zu rounds: search+prune %.1fs, group %.1fs, reverse %.1fs, total %.1fs (%d threads)\n",
+            jobs.size(), total_items, round_no, tA, tB, tC, now() - t0, nthr);
+  // final neighbour sort by distance to the node (vamana/index.h:131-134), all nodes of all partitions
+  std::vector<int64_t> base(jobs.size() + 1, 0);
+  for (size_t j = 0; j < jobs.size(); j++) base[j + 1] = base[j] + jobs[j].V.n;
+  parallel_for(base.back(), nthr, [&](int64_t g) {
+    size_t j = std::upper_bound(base.begin(), base.end(), g) - base.begin() - 1;
+    Job &J = jobs[j];
+    const int64_t i = g - base[j];
+    int32_t *row = J.G->row(i);
     std::vector<uint64_t> nb((size_t)row[0]);
-    for (int32_t j = 0; j < row[0]; j++) nb[j] = mkkey(V.dist(i, row[1 + j]), row[1 + j]);
+    for (int32_t x = 0; x < row[0]; x++) nb[x] = mkkey(J.V.dist(i, row[1 + x]), row[1 + x]);
     std::sort(nb.begin(), nb.end());
-    for (int32_t j = 0; j < row[0]; j++) row[1 + j] = key_id(nb[j]);
+    for (int32_t x = 0; x < row[0]; x++) row[1 + x] = key_id(nb[x]);
   });
+}
+
+void vamana_build(const float *pts, int64_t stride, int64_t d, int metric, int64_t start, int64_t n,
+                  int64_t R, int64_t L, double alpha, HostGraph &G, int threads) {
+  std::vector<Job> jobs(1);
+  jobs[0].V = BuildView{pts, stride, d, metric, start, n, R, L, alpha};
+  jobs[0].G = &G;
+  build_many(jobs, threads);
 }
 
 // ------------------------------------------------------------------------------------------------
 // index layout
 // ------------------------------------------------------------------------------------------------
-static void obtain_graph(HostIndex &H, HostPart &P, int threads, bool keep) {
-  const BuildSpec &s = H.spec;
-  P.lo = *std::min_element(H.labels.begin() + P.start, H.labels.begin() + P.start + P.n);
-  P.hi = *std::max_element(H.labels.begin() + P.start, H.labels.begin() + P.start + P.n);
-  std::string fn = s.cache.empty() ? std::string() : graph_file_name(s, P.lo, P.hi, P.n);
-  if (!fn.empty() && exists(fn)) {
-    if (!keep) return;
-    if (!graph_file_load(fn, P.g)) throw std::runtime_error("cannot read graph cache file " + fn);
-    if (P.g.n != P.n) throw std::runtime_error("graph cache file has the wrong size: " + fn);
-    return;
-  }
-  vamana_build(H.pts.data(), s.stride, s.d, s.metric, P.start, P.n, s.R, s.L, s.alpha, P.g, threads);
-  if (!fn.empty() && !graph_file_save(fn, P.g)) throw std::runtime_error("cannot write graph cache file " + fn);
-  if (!keep) {
-    P.g.rows.clear();
-    P.g.rows.shrink_to_fit();
-  }
-}
-
-void build_host_index(HostIndex &H, const float *points, const float *labels, int shard, int nshards) {
+void build_host_index(HostIndex &H, const float *points, const float *labels, int shard, int nshards,
+                      std::vector<HostPart *> *pending) {
   BuildSpec &s = H.spec;
   if (s.n <= 0 || s.d <= 0) throw std::runtime_error("empty point set");
   if (s.threads <= 0) s.threads = default_threads();
@@ -587,24 +660,74 @@ void build_host_index(HostIndex &H, const float *points, const float *labels, in
   if (!H.vamana_leaves) return;
   if (s.R > 64) throw std::runtime_error("max_degree > 64 is not supported by the gfx950 search kernel");
 
-  // graphs: big partitions one after another with a parallel build inside, small ones in parallel
+  // graphs: load what the cache holds, build the rest in lock-step, publish to the cache
   const bool sharded = nshards > 0;
-  std::vector<size_t> big, small;
+  const bool keep = !sharded;
+  std::vector<HostPart *> want;
   for (size_t t = 0; t < todo.size(); t++) {
     if (sharded && (int)(t % (size_t)nshards) != shard) continue;
-    const HostPart &P = H.levels[todo[t].first][todo[t].second];
-    (P.n >= 16384 ? big : small).push_back(t);
+    want.push_back(&H.levels[todo[t].first][todo[t].second]);
   }
-  for (size_t t : big) obtain_graph(H, H.levels[todo[t].first][todo[t].second], s.threads, !sharded);
   std::mutex emu;
   std::string err;
-  parallel_for((int64_t)small.size(), s.threads, [&](int64_t i) {
+  std::vector<char> need(want.size(), 0);
+  parallel_for((int64_t)want.size(), s.threads, [&](int64_t i) {
     try {
-      size_t t = small[i];
-      obtain_graph(H, H.levels[todo[t].first][todo[t].second], 1, !sharded);
+      HostPart &P = *want[i];
+      P.lo = *std::min_element(H.labels.begin() + P.start, H.labels.begin() + P.start + P.n);
+      P.hi = *std::max_element(H.labels.begin() + P.start, H.labels.begin() + P.start + P.n);
+      const std::string fn = s.cache.empty() ? std::string() : graph_file_name(s, P.lo, P.hi, P.n);
+      if (!fn.empty() && exists(fn)) {
+        if (!keep) return;
+        if (!graph_file_load(fn, P.g)) throw std::runtime_error("cannot read graph cache file " + fn);
+        if (P.g.n != P.n) throw std::runtime_error("graph cache file has the wrong size: " + fn);
+        return;
+      }
+      need[i] = 1;
     } catch (std::exception &e) {
       std::lock_guard<std::mutex> lk(emu);
       err = e.what();
+    }
+  });
+  if (!err.empty()) throw std::runtime_error(err);
+  std::vector<HostPart *> todo_build;
+  for (size_t i = 0; i < want.size(); i++)
+    if (need[i]) todo_build.push_back(want[i]);
+  if (pending) {
+    *pending = todo_build;
+    return;
+  }
+  build_pending_on_host(H, todo_build);
+  save_built_graphs(H, todo_build, keep);
+}
+
+void build_pending_on_host(HostIndex &H, std::vector<HostPart *> &pending) {
+  const BuildSpec &s = H.spec;
+  std::vector<Job> jobs;
+  for (HostPart *P : pending) {
+    Job J;
+    J.V = BuildView{H.pts.data(), s.stride, s.d, s.metric, P->start, P->n, s.R, s.L, s.alpha};
+    J.G = &P->g;
+    jobs.push_back(std::move(J));
+  }
+  if (!jobs.empty()) build_many(jobs, s.threads);
+}
+
+void save_built_graphs(HostIndex &H, std::vector<HostPart *> &built, bool keep) {
+  const BuildSpec &s = H.spec;
+  if (s.cache.empty()) return;
+  std::mutex emu;
+  std::string err;
+  parallel_for((int64_t)built.size(), s.threads, [&](int64_t i) {
+    HostPart &P = *built[i];
+    const std::string fn = graph_file_name(s, P.lo, P.hi, P.n);
+    if (!graph_file_save(fn, P.g)) {
+      std::lock_guard<std::mutex> lk(emu);
+      err = "cannot write graph cache file " + fn;
+    }
+    if (!keep) {
+      P.g.rows.clear();
+      P.g.rows.shrink_to_fit();
     }
   });
   if (!err.empty()) throw std::runtime_error(err);

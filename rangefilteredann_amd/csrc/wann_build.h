@@ -68,7 +68,11 @@ void vamana_build(const float *pts, int64_t stride, int64_t d, int metric, int64
 
 // Sort, lay out the tree and obtain every partition's graph (cache or build).
 // shard/nshards >= 0: only materialise (build + save) partitions p with p % nshards == shard.
+// pending != nullptr: graphs missing from the cache are NOT built here but returned in *pending
+// (the caller builds them, on the GPU or with build_pending_on_host, then calls save_built_graphs).
 void build_host_index(HostIndex &H, const float *points, const float *labels, int shard = -1,
-                      int nshards = 0);
+                      int nshards = 0, std::vector<HostPart *> *pending = nullptr);
+void build_pending_on_host(HostIndex &H, std::vector<HostPart *> &pending);
+void save_built_graphs(HostIndex &H, std::vector<HostPart *> &built, bool keep);
 
 }  // namespace wann

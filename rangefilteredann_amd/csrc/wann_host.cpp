@@ -21,6 +21,8 @@
 #include "../../include/wann.h"
 #include "wann_build.h"
 #include "wann_device.h"
+#include "wann_gpu_build.h"
+#include "wann_hip_util.h"
 
 using namespace wann;
 
@@ -31,39 +33,6 @@ int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
 }
-
-struct HipError : std::runtime_error {
-  using std::runtime_error::runtime_error;
-};
-#define HIP_CHECK(expr)                                                                        \
-  do {                                                                                         \
-    hipError_t _e = (expr);                                                                    \
-    if (_e != hipSuccess)                                                                      \
-      throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));                       \
-  } while (0)
-
-template <typename T>
-struct DevBuf {
-  T *p = nullptr;
-  size_t cap = 0;
-  ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  void ensure(size_t n) {
-    if (n <= cap) return;
-    release();
-    HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
-    cap = n;
-  }
-  void upload(const std::vector<T> &v) {
-    ensure(v.size());
-    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  }
-  size_t bytes() const { return cap * sizeof(T); }
-};
 
 int usable_devices() {
   int n = 0;
@@ -222,7 +191,10 @@ void upload_index(wann_index &I) {
     for (auto &lv : H.levels)
       for (auto &P : lv) {
         const PartDesc &pd = I.parts[pi++];
-        if (P.g.n != P.n) throw std::runtime_error("partition graph missing");
+        if (P.g.n != P.n) {  // not in the cache: built on the device afterwards, rows start empty
+          HIP_CHECK(hipMemset(I.d_graph.p + pd.row_base * v.rs, 0xFF, (size_t)pd.n * v.rs * 4));
+          continue;
+        }
         for (int64_t r0 = 0; r0 < P.n; r0 += (int64_t)stage_rows) {
           int64_t cnt = std::min<int64_t>((int64_t)stage_rows, P.n - r0);
           stage.resize((size_t)cnt * v.rs);
@@ -459,6 +431,42 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
                              " queries; not implemented on the device yet");
 }
 
+// Graphs missing from the cache: built on the GPU straight into the adjacency pool (default) or, with
+// WANN_HOST_BUILD=1 or after a device-side overflow, by the host builder and then uploaded.
+void upload_part_rows(wann_index &I, const HostPart &P, const PartDesc &pd) {
+  const int rs = I.view.rs;
+  std::vector<int32_t> stage((size_t)P.n * rs);
+  convert_rows(P.g, rs, stage.data());
+  HIP_CHECK(hipMemcpy(I.d_graph.p + pd.row_base * rs, stage.data(), stage.size() * 4, hipMemcpyHostToDevice));
+}
+
+void build_pending(wann_index &I, std::vector<HostPart *> &pending) {
+  HostIndex &H = I.H;
+  const BuildSpec &s = H.spec;
+  std::vector<GpuBuildTarget> targets;
+  size_t pi = 0;
+  for (auto &lv : H.levels)
+    for (auto &P : lv) {
+      if (std::find(pending.begin(), pending.end(), &P) != pending.end()) targets.push_back(GpuBuildTarget{(int32_t)pi, &P});
+      pi++;
+    }
+  bool on_host = getenv("WANN_HOST_BUILD") != nullptr;
+  if (!on_host) {
+    try {
+      gpu_build_graphs(I.view, I.d_graph.p, I.parts, targets, s.R, s.L, s.alpha, I.num_cus, s.threads, I.own_stream);
+    } catch (std::runtime_error &e) {
+      if (std::string(e.what()).find("gpu build overflow") == std::string::npos) throw;
+      fprintf(stderr, "[wann] %s; rebuilding on the host\n", e.what());
+      on_host = true;
+    }
+  }
+  if (on_host) {
+    build_pending_on_host(H, pending);
+    for (auto &t : targets) upload_part_rows(I, *t.part, I.parts[t.part_index]);
+  }
+  save_built_graphs(H, pending, true);
+}
+
 BuildSpec make_spec(int kind, int metric, int64_t n, int64_t d, int32_t cutoff, double split_factor,
                     double shift_factor, const wann_build_params *bp, int threads) {
   BuildSpec s;
@@ -508,8 +516,10 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
   try {
     I->device = device;
     I->H.spec = make_spec(kind, metric, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
-    build_host_index(I->H, (const float *)points, labels);
+    std::vector<HostPart *> pending;
+    build_host_index(I->H, (const float *)points, labels, -1, 0, &pending);
     upload_index(*I);
+    if (!pending.empty()) build_pending(*I, pending);
   } catch (HipError &e) {
     fail(WANN_ERR_HIP, e.what());
     return nullptr;

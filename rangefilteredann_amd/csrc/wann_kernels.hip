@@ -18,250 +18,9 @@
 #include <stdint.h>
 
 #include "wann_device.h"
+#include "wann_wave.h"
 
 namespace wann {
-
-typedef unsigned long long u64;
-
-#define WAVE_SYNC()                                            \
-  do {                                                         \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     \
-    __builtin_amdgcn_wave_barrier();                           \
-  } while (0)
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ u64 rdlane64(u64 v, int l) {
-  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-  return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ int ctz64(u64 m) { return __builtin_ctzll(m); }
-__device__ __forceinline__ int popc64(u64 m) { return __builtin_popcountll(m); }
-__device__ __forceinline__ u64 lanemask_lt() { return ((u64)1 << lane_id()) - 1; }
-
-// One work-list ticket per wave.  The lane election must not look loop invariant to the compiler:
-// hipcc (ROCm 7.2) otherwise unswitches the persistent loop on `lane == 0` and the non-zero lanes
-// spin on a stale ticket (readfirstlane then runs under a partial exec mask).  The volatile asm
-// keeps the predicate inside the loop.
-__device__ __forceinline__ int wave_ticket(int32_t *cursor) {
-  int lane;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-  int t = 0;
-  if (lane == 0) t = atomicAdd(cursor, 1);
-  return __builtin_amdgcn_readfirstlane(t);
-}
-
-// order preserving float -> uint32 (ascending)
-__device__ __forceinline__ uint32_t fkey(float f) {
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float funkey(uint32_t k) {
-  return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
-}
-
-// parlay::hash64_2 (parlay/utilities.h:145-150)
-__device__ __forceinline__ u64 hash64_2(u64 x) {
-  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
-  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
-  return x ^ (x >> 31);
-}
-
-// --------------------------------------------------------------------------------------------
-// distances in the reference's evaluation order
-// --------------------------------------------------------------------------------------------
-// Squared L2 (NSGDist.h:33-69): 8 accumulators (the AVX lanes); a lane PAIR owns one candidate:
-// lane h = lane&1 carries accumulators 4h..4h+3 and walks the 8-float blocks in the reference's
-// order (odd block count: last block first).  Returns the full distance in the odd lane.
-template <int NB>
-__device__ __forceinline__ float l2_pair(const float *__restrict__ prow, const float *qv, int D8,
-                                         int h, bool active) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (active) {
-    const bool odd = D8 & 1;
-    for (int i0 = 0; i0 < D8; i0 += NB) {
-      float4 buf[NB];
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        int i = i0 + j;
-        if (i < D8) {
-          int b = odd ? (i == 0 ? D8 - 1 : i - 1) : i;
-          buf[j] = *reinterpret_cast<const float4 *>(prow + 8 * b + 4 * h);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        int i = i0 + j;
-        if (i < D8) {
-          int b = odd ? (i == 0 ? D8 - 1 : i - 1) : i;
-          float4 q = *reinterpret_cast<const float4 *>(qv + 8 * b + 4 * h);
-          float t;
-          t = buf[j].x - q.x; a0 = fmaf(t, t, a0);
-          t = buf[j].y - q.y; a1 = fmaf(t, t, a1);
-          t = buf[j].z - q.z; a2 = fmaf(t, t, a2);
-          t = buf[j].w - q.w; a3 = fmaf(t, t, a3);
-        }
-      }
-    }
-  }
-  float s = ((a0 + a1) + a2) + a3;          // even lane: ((l0+l1)+l2)+l3
-  float other = __shfl_xor(s, 1);           // odd lane receives the even lane's partial
-  return (((other + a0) + a1) + a2) + a3;   // odd lane: ((((s+l4)+l5)+l6)+l7)
-}
-
-// Negative inner product (mips_point.h:60-66 as compiled): running scalar, products rounded then
-// added in index order for the first 8*floor(d/8) elements, fused for the tail.  One lane per row.
-template <int NB>
-__device__ __forceinline__ float mips_lane(const float *__restrict__ prow, const float *qv, int d,
-                                           bool active) {
-  float r = 0.f;
-  if (active) {
-    const int nch = (d + 3) >> 2;
-    const int dv = d & ~7;
-    for (int c0 = 0; c0 < nch; c0 += NB) {
-      float4 buf[NB];
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        int c = c0 + j;
-        if (c < nch) buf[j] = *reinterpret_cast<const float4 *>(prow + 4 * c);
-      }
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        int c = c0 + j;
-        if (c < nch) {
-          float4 q = *reinterpret_cast<const float4 *>(qv + 4 * c);
-          if (4 * c + 3 < dv) {
-            r = __fadd_rn(r, __fmul_rn(q.x, buf[j].x));
-            r = __fadd_rn(r, __fmul_rn(q.y, buf[j].y));
-            r = __fadd_rn(r, __fmul_rn(q.z, buf[j].z));
-            r = __fadd_rn(r, __fmul_rn(q.w, buf[j].w));
-          } else {  // dv is a multiple of 8, so a chunk is entirely vector part or entirely tail
-            r = fmaf(q.x, buf[j].x, r);
-            r = fmaf(q.y, buf[j].y, r);
-            r = fmaf(q.z, buf[j].z, r);
-            r = fmaf(q.w, buf[j].w, r);
-          }
-        }
-      }
-    }
-  }
-  return -r;
-}
-
-// Distances of `cnt` rows whose (sorted-order) row numbers sit in ids_lds[0..cnt): afterwards lane
-// s < cnt holds the distance of row s.  scratch_lds: 64 floats.
-template <int METRIC>
-__device__ __forceinline__ float wave_distances(const IndexView &ix, const int32_t *ids_lds,
-                                                float *scratch_lds, const float *qv, int cnt,
-                                                int64_t row_off) {
-  const int lane = lane_id();
-  if (METRIC == 1) {
-    bool act = lane < cnt;
-    int id = act ? ids_lds[lane] : 0;
-    const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
-    return mips_lane<8>(prow, qv, ix.d, act);
-  } else {
-    const int D8 = (ix.d + 7) >> 3;
-    const int h = lane & 1;
-    for (int base = 0; base < cnt; base += 32) {
-      int s = base + (lane >> 1);
-      bool act = s < cnt;
-      int id = act ? ids_lds[s] : 0;
-      const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
-      float dist = l2_pair<8>(prow, qv, D8, h, act);
-      if (act && h) scratch_lds[s] = dist;
-    }
-    WAVE_SYNC();
-    float r = (lane < cnt) ? scratch_lds[lane] : 0.f;
-    WAVE_SYNC();
-    return r;
-  }
-}
-
-// --------------------------------------------------------------------------------------------
-// sorted-list merge: insert the candidates flagged `pass` (key = fkey(dist)<<32 | id<<1) into the
-// sorted list beam[0..m) of capacity B, dropping candidates already present (same id and dist),
-// exactly like std::set_union + truncate (beamSearch.h:148-157).  Bit 0 of an entry is its
-// "visited" flag and is ignored by comparisons.  Returns the new size; *first_pos receives the
-// position of the first inserted element (or the old size when nothing was inserted).
-// cand_key: 64 u64 of per-wave LDS scratch.
-// --------------------------------------------------------------------------------------------
-template <typename BeamPtr>
-__device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass, u64 key,
-                                          u64 *cand_key, int *first_pos) {
-  const int lane = lane_id();
-  *first_pos = m;
-  u64 smask = ballot64(pass);
-  if (smask == 0) return m;
-  int rank = 0;
-  for (u64 mm = smask; mm; mm &= mm - 1) {
-    int l = ctz64(mm);
-    u64 kl = rdlane64(key, l);
-    rank += (kl < key || (kl == key && l < lane)) ? 1 : 0;
-  }
-  if (pass) cand_key[rank] = key;
-  WAVE_SYNC();
-  const int c = popc64(smask);
-  const bool mine = lane < c;
-  u64 ck = mine ? cand_key[lane] : ~0ull;
-  // lower bound of ck in beam[0..m)
-  int lo = 0, hi = m;
-  const int iters = 32 - __builtin_clz(m | 1) + 1;
-  for (int it = 0; it < iters; it++) {
-    if (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      u64 bv = beam[mid] | 1ull;
-      if (bv < (ck | 1ull)) lo = mid + 1;
-      else hi = mid;
-    }
-  }
-  const int pos = lo;
-  // std::set_union keeps max(copies in beam, copies among candidates) of equal elements: the j-th
-  // copy of a candidate key is dropped iff the beam already holds more than j copies.  (Copies
-  // arise when a row lists a node twice -- the reference's builder can append the start point
-  // twice -- and the lossy filter lets both through.)
-  bool dup = false;
-  if (mine) {
-    int j = 0, bx = 0;
-    for (int l = lane - 1; l >= 0 && cand_key[l] == ck; l--) j++;
-    while (pos + bx < m && ((beam[pos + bx] | 1ull) == (ck | 1ull))) bx++;
-    dup = j < bx;
-  }
-  WAVE_SYNC();
-  const u64 nd = ballot64(mine && !dup);
-  const int cp = popc64(nd);
-  if (cp == 0) return m;
-  const int pre = popc64(nd & lanemask_lt());
-  const int p0 = rdlane(pos, ctz64(nd));
-  const int span = m - p0;
-  if (span > 0) {
-    for (int base = p0 + ((span - 1) & ~63); base >= p0; base -= 64) {
-      int x = base + lane;
-      bool act = x < m;
-      u64 e = act ? beam[x] : 0ull;
-      int sx = 0;
-      for (u64 mm = nd; mm; mm &= mm - 1) {
-        int pl = rdlane(pos, ctz64(mm));
-        sx += (pl <= x) ? 1 : 0;
-      }
-      WAVE_SYNC();
-      int nx = x + sx;
-      if (act && nx < B) beam[nx] = e;
-      WAVE_SYNC();
-    }
-  }
-  if (mine && !dup) {
-    int np = pos + pre;
-    if (np < B) beam[np] = ck;
-  }
-  WAVE_SYNC();
-  *first_pos = p0;
-  int nm = m + cp;
-  return nm < B ? nm : B;
-}
 
 // --------------------------------------------------------------------------------------------
 // k_search
@@ -288,145 +47,30 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
   const int B = A.B;
   const int bits = A.bits;
   const int per_wave = lds_bytes_per_wave(B, bits, ix.stride, TABLE_LDS, BEAM_LDS);
-  unsigned char *base = smem + (size_t)wib * per_wave;
-  float *qv = reinterpret_cast<float *>(base);
-  int off = (ix.stride * 4 + 15) & ~15;
-  u64 *cand_key = reinterpret_cast<u64 *>(base + off);
-  off += 64 * 8;
-  int32_t *cand_id = reinterpret_cast<int32_t *>(base + off);
-  off += 64 * 4;
-  float *cand_dist = reinterpret_cast<float *>(base + off);
-  off += 64 * 4;
-  u64 *lbeam = reinterpret_cast<u64 *>(base + off);
-  if (BEAM_LDS) off += ((B + 1) & ~1) * 8;
-  int32_t *ltable = reinterpret_cast<int32_t *>(base + off);
-
-  const uint32_t tmask = (1u << bits) - 1u;
+  const WaveLds L = carve_wave_lds(smem + (size_t)wib * per_wave, ix.stride, B, BEAM_LDS);
+  u64 *gbeam = BEAM_LDS ? nullptr : A.g_beam + (size_t)slot * A.g_beam_cap;
+  int32_t *gtable = TABLE_LDS ? nullptr : A.g_table + ((size_t)slot << bits);
   const int total = *A.list_count;
-#define TRACE(v)                                                                                   \
-  do {                                                                                             \
-    if (A.trace && lane == 0)                                                                      \
-      __hip_atomic_store(&A.trace[slot], (unsigned int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
-  } while (0)
-  TRACE(1);
 
   for (;;) {
     const int t = wave_ticket(A.cursor);
-    TRACE(0x100 + t);
     if (t >= total) break;
     const int ti = A.list[t];
     const Task task = A.tasks[ti];
     const PartDesc part = ix.parts[task.part];
-    TRACE(2);
     const int64_t qrow = task.query;
     const int64_t qid = A.raw ? A.raw_qids[qrow] : (A.qid_base + qrow);
     const int64_t row_off = part.start;
 
-    // stage the query (zero padded) and reset the seen-filter
-    for (int i = lane; i < ix.stride; i += 64) qv[i] = (i < ix.d) ? A.queries[qrow * ix.d + i] : 0.f;
-    if (TABLE_LDS) {
-      for (int i = lane; i < (1 << bits); i += 64) ltable[i] = -1;
-    } else {
-      int4 *gt = reinterpret_cast<int4 *>(A.g_table + ((size_t)slot << bits));
-      for (int i = lane; i < (1 << (bits - 2)); i += 64) gt[i] = make_int4(-1, -1, -1, -1);
-    }
+    // stage the query (zero padded)
+    for (int i = lane; i < ix.stride; i += 64) L.qv[i] = (i < ix.d) ? A.queries[qrow * ix.d + i] : 0.f;
     WAVE_SYNC();
+    int m;
+    long long nvis, ncmp;
+    wave_beam_search<METRIC, TABLE_LDS, BEAM_LDS, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit,
+                                                         A.degree_limit, nullptr, 0, m, nvis, ncmp);
+    auto beam_ld = [&](int i) -> u64 { return BEAM_LDS ? L.lbeam[i] : gbeam[i]; };
 
-    TRACE(3);
-    // frontier = {start node 0} (beamSearch.h:80-82)
-    if (lane == 0) cand_id[0] = 0;
-    WAVE_SYNC();
-    float d0 = wave_distances<METRIC>(ix, cand_id, cand_dist, qv, 1, row_off);
-    d0 = __shfl(d0, 0);
-    TRACE(4);
-    int m = 1, p = 0;
-    long long nvis = 0, ncmp = 1;
-
-    auto beam_ld = [&](int i) -> u64 {
-      if (BEAM_LDS) return lbeam[i];
-      return A.g_beam[(size_t)slot * A.g_beam_cap + i];
-    };
-    auto beam_st = [&](int i, u64 v) {
-      if (BEAM_LDS) lbeam[i] = v;
-      else A.g_beam[(size_t)slot * A.g_beam_cap + i] = v;
-    };
-    if (lane == 0) beam_st(0, ((u64)fkey(d0) << 32));
-    WAVE_SYNC();
-
-    while (p < m && nvis < A.limit) {
-      TRACE(0x10000 + (int)nvis);
-      // ---- visit the closest unvisited beam entry (beamSearch.h:111-117)
-      const u64 curkey = beam_ld(p);
-      const int cur = (int)((uint32_t)curkey >> 1);
-      if (lane == 0) beam_st(p, curkey | 1ull);
-      nvis++;
-
-      // ---- adjacency row, coalesced (graph.h:198); -1 = unused slot
-      int a = -1;
-      if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
-      bool valid = (a >= 0) && (lane < A.degree_limit) && ((int64_t)a != qid);
-
-      // ---- lossy direct-mapped "seen" filter, sequential semantics emulated exactly
-      //      (beamSearch.h:68-73,126-131): lane i sees the id left in its slot by the nearest
-      //      preceding lane of the row that hashed to the same slot, else the table's old value;
-      //      the last lane of each slot class leaves its id in the table.
-      const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
-      int old = -1;
-      if (valid) old = TABLE_LDS ? ltable[loc] : A.g_table[((size_t)slot << bits) + loc];
-      u64 eq = ballot64(valid);
-      for (int b = 0; b < bits; b++) {
-        bool bit = (loc >> b) & 1u;
-        u64 bm = ballot64(valid && bit);
-        eq &= bit ? bm : ~bm;
-      }
-      const u64 lower = eq & lanemask_lt();
-      const u64 higher = (lane == 63) ? 0ull : (eq >> (lane + 1));
-      int prev_lane = lower ? (63 - __builtin_clzll(lower)) : lane;
-      int prev_val = __shfl(a, prev_lane);
-      if (!lower) prev_val = old;
-      const bool seen = valid && (prev_val == a);
-      WAVE_SYNC();
-      if (valid && higher == 0) {
-        if (TABLE_LDS) ltable[loc] = a;
-        else A.g_table[((size_t)slot << bits) + loc] = a;
-      }
-      const bool keep = valid && !seen;
-      const u64 kmask = ballot64(keep);
-      const int nk = popc64(kmask);
-      if (keep) cand_id[popc64(kmask & lanemask_lt())] = a;
-      WAVE_SYNC();
-      ncmp += nk;
-
-      // ---- score the kept neighbours (beamSearch.h:135-145)
-      float cutoff = 2147483648.0f;  // (float)INT_MAX
-      if (m >= B) cutoff = funkey((uint32_t)(beam_ld(m - 1) >> 32));
-      float dist = wave_distances<METRIC>(ix, cand_id, cand_dist, qv, nk, row_off);
-      int cid = (lane < nk) ? cand_id[lane] : 0;
-      WAVE_SYNC();
-      const bool pass = (lane < nk) && (dist < cutoff);
-      const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);
-
-      // ---- sort + set_union + truncate (beamSearch.h:148-157)
-      int p0;
-      if (BEAM_LDS) m = wave_merge(lbeam, m, B, pass, key, cand_key, &p0);
-      else m = wave_merge(A.g_beam + (size_t)slot * A.g_beam_cap, m, B, pass, key, cand_key, &p0);
-
-      // ---- next = first beam entry not yet visited (beamSearch.h:175-178)
-      int sp = p < p0 ? p : p0;
-      p = m;
-      while (sp < m) {
-        int x = sp + lane;
-        bool un = (x < m) && !(beam_ld(x) & 1ull);
-        u64 bm = ballot64(un);
-        if (bm) {
-          p = sp + ctz64(bm);
-          break;
-        }
-        sp += 64;
-      }
-    }
-
-    TRACE(5);
     if (lane == 0) {
       atomicAdd(&A.ctr->beam_searches, 1ull);
       atomicAdd(&A.ctr->hops, (unsigned long long)nvis);
@@ -444,7 +88,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
         A.raw_hops[qrow] = nvis;
         A.raw_cmps[qrow] = ncmp;
       }
-      TRACE(6);
       continue;
     }
 

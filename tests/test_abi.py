@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads and exports every symbol include/wann.h declares; without a GPU
+every compute entry point fails loudly (there is no CPU fallback in the product)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import REPO
+
+
+def declared_functions():
+    src = open(os.path.join(REPO, "include", "wann.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wann_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(wa):
+    import rangefilteredann_amd
+    lib = ctypes.CDLL(rangefilteredann_amd.lib_path())
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"libwann.so does not export {n}"
+    assert lib.wann_abi_version() == 1
+
+
+def test_python_surface_matches_reference_names(wa):
+    # python_bindings/python_bindings.cpp:111-157,204-213 + variant names :67-86
+    for agn in ("FloatEuclidian", "FloatMips", "UInt8Euclidian", "UInt8Mips", "Int8Euclidian", "Int8Mips"):
+        for cls in ("PrefilterIndex", "RangeFilterTreeIndex", "PostfilterVamanaIndex", "VamanaRangeFilterTreeIndex",
+                    "SuperOptimizedPostfilterTreeIndex"):
+            assert hasattr(wa, cls + agn)
+    qp = wa.QueryParams(k=10, beam_width=40, cut=1.35, limit=10_000_000, degree_limit=10_000, final_beam_multiply=1,
+                        postfiltering_max_beam=10000, min_query_to_bucket_ratio=None, verbose=False)
+    bp = wa.BuildParams(max_degree=64, limit=500, alpha=1.0, cache_path="index_cache/x/")
+    assert qp is not None and bp is not None
+    assert wa.defaults.GRAPH_DEGREE == 64
+
+
+def test_no_gpu_means_loud_failure(wa):
+    if wa.device_count() > 0:
+        pytest.skip("a GPU is present")
+    X = np.zeros((16, 8), dtype=np.float32)
+    lab = np.arange(16, dtype=np.float32)
+    for cls in ("VamanaRangeFilterTreeIndexFloatEuclidian", "PrefilterIndexFloatMips", "SuperOptimizedPostfilterTreeIndexFloatMips"):
+        with pytest.raises(RuntimeError, match="no usable gfx950 device"):
+            getattr(wa, cls)(X, lab)
+    with pytest.raises(RuntimeError, match="no usable gfx950 device"):
+        wa.raw_beam_search(0, X, np.zeros((16, 5), dtype=np.int32), 0, X[:2], np.arange(2), 4)
+
+
+def test_uint8_variants_raise(wa):
+    X = np.zeros((16, 8), dtype=np.uint8)
+    with pytest.raises(RuntimeError, match="float only"):
+        wa.VamanaRangeFilterTreeIndexUInt8Euclidian(X, np.arange(16, dtype=np.float32))

@@ -1,0 +1,74 @@
+"""CPU: the N > 1 path (query shards + all-gather of the per-shard top-k) with world_size 2 on the
+gloo backend.  The local search function is the oracle here; on the GPU box it is the HIP path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import REPO, distinct_labels, sift_like, windows
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nq, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WANN_NO_TORCH="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search
+    n, d = 1500, 32
+    g = sift_like(n, d, 1)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 2)
+    W = windows(labels, nq, -2, 3).astype(np.float32)
+    idx = orc.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=300, split_factor=2, build_params=orc.BuildParams(16, 32, 1.0, ""), threads=2)
+    qp = orc.QueryParams(10, 20)
+    calls = []
+
+    def search_fn(q, r, base):
+        calls.append((int(base), q.shape[0]))
+        # the oracle numbers queries from 0: emulate the global numbering by searching a padded batch
+        full_q = np.zeros((base + q.shape[0], d), dtype=np.float32)
+        full_r = np.zeros((base + q.shape[0], 2), dtype=np.float32)
+        full_q[base:], full_r[base:] = q.numpy(), r.numpy()
+        full_r[:base] = (5.0, 6.0)  # empty windows: no work
+        ids, dists = idx.batch_search(full_q, full_r, base + q.shape[0], "optimized_postfilter", qp)
+        return torch.from_numpy(ids[base:].view(np.int32).copy()), torch.from_numpy(dists[base:].copy())
+
+    ids, dists = sharded_batch_search(search_fn, torch.from_numpy(Q), torch.from_numpy(W), 10)
+    lo, hi = shard_bounds(nq, world, rank)
+    assert calls == [(lo, hi - lo)]
+    eids, edists = idx.batch_search(Q, W, nq, "optimized_postfilter", qp)
+    ok = np.array_equal(ids.numpy().view(np.uint32), eids) and np.array_equal(dists.numpy(), edists)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [64, 77])
+def test_two_rank_sharded_search_equals_single_process(oracle, tmp_path, nq):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), nq, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"ok{r}").read() == "1"
+
+
+def test_shard_bounds_cover_everything():
+    from rangefilteredann_amd.distributed import shard_bounds, shard_capacity
+    for nq in (0, 1, 7, 8, 10000, 10001):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(nq, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == nq
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in edges) <= shard_capacity(nq, world)

@@ -193,3 +193,33 @@ def test_device_resident_call_matches_host_call(wa, gpu, tmp_path):
     idx.batch_search_device(tq[half:].data_ptr(), tw[half:].data_ptr(), nq - half, half, "optimized_postfilter", qp,
                             tids[half:].data_ptr(), tdist[half:].data_ptr(), 0)
     assert np.array_equal(tids.cpu().numpy().view(np.uint32), ids)
+
+
+# ------------------------------------------------------------------------------------------
+# GPU Vamana build: byte-identical graph files to the host builder (hence to the oracle's builder)
+# ------------------------------------------------------------------------------------------
+BUILD_CASES = [
+    ("VamanaRangeFilterTreeIndex", "FloatEuclidian", sift_like, 128, 6000, dict(cutoff=500, split_factor=2), 32, 64),
+    ("VamanaRangeFilterTreeIndex", "FloatMips", unit_mixture, 100, 4000, dict(cutoff=400, split_factor=2), 24, 48),
+    ("SuperOptimizedPostfilterTreeIndex", "FloatEuclidian", sift_like, 40, 3000, dict(cutoff=300, split_factor=2, shift_factor=0.5), 16, 100),
+    ("PostfilterVamanaIndex", "FloatEuclidian", sift_like, 64, 20000, dict(), 64, 500),
+]
+
+
+@pytest.mark.parametrize("kind,sfx,gen,d,n,kw,R,L", BUILD_CASES)
+def test_gpu_builder_matches_host_builder(wa, gpu, tmp_path, monkeypatch, kind, sfx, gen, d, n, kw, R, L):
+    import os
+    X = gen(n, d, 77)(n)
+    labels = distinct_labels(n, 13)
+    labkw = "filters" if kind == "PostfilterVamanaIndex" else "filter_values"
+    gdir, hdir = str(tmp_path / "gpu") + "/", str(tmp_path / "host") + "/"
+    os.makedirs(gdir), os.makedirs(hdir)
+    monkeypatch.delenv("WANN_HOST_BUILD", raising=False)
+    getattr(wa, kind + sfx)(X, **{labkw: labels}, build_params=wa.BuildParams(R, L, 1.0, gdir), **kw)
+    monkeypatch.setenv("WANN_HOST_BUILD", "1")
+    getattr(wa, kind + sfx)(X, **{labkw: labels}, build_params=wa.BuildParams(R, L, 1.0, hdir), **kw)
+    gf, hf = sorted(os.listdir(gdir)), sorted(os.listdir(hdir))
+    assert gf == hf and len(gf) > 0
+    for f in gf:
+        a, b = open(gdir + f, "rb").read(), open(hdir + f, "rb").read()
+        assert a == b, f"{f}: GPU-built graph differs from the host-built one"

@@ -1,0 +1,53 @@
+"""CPU, authoring container only: the oracle against the REAL reference built from /root/reference
+(oracle/_ref, `make -C oracle ref`).  Skipped where no reference build is present (the committed
+golden vectors in tests/golden/ carry the same pin everywhere else)."""
+import os
+
+import numpy as np
+import pytest
+
+from util import distinct_labels, quiet_stdout, sift_like, unit_mixture, windows
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    os.environ.setdefault("PARLAY_NUM_THREADS", "4")
+    mod = oracle.load_reference()
+    if mod is None:
+        pytest.skip("no reference build under oracle/_ref")
+    return mod
+
+
+KINDS = ["VamanaRangeFilterTreeIndex", "SuperOptimizedPostfilterTreeIndex", "PostfilterVamanaIndex", "RangeFilterTreeIndex", "PrefilterIndex"]
+
+
+@pytest.mark.parametrize("metric,gen,d", [("Euclidian", sift_like, 128), ("mips", unit_mixture, 100), ("Euclidian", unit_mixture, 104)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_oracle_equals_reference(oracle, ref, tmp_path, metric, gen, d, kind):
+    n, nq = 2500, 60
+    g = gen(n, d, 31)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 12)
+    sfx = "FloatMips" if metric == "mips" else "FloatEuclidian"
+    kw = dict(cutoff=250, split_factor=2) if "Tree" in kind else {}
+    if kind.startswith("Super"):
+        kw["shift_factor"] = 0.5
+    labkw = "filters" if kind == "PostfilterVamanaIndex" else "filter_values"
+    cache = str(tmp_path) + "/"
+    with quiet_stdout():  # the reference builds and writes the graph cache; the oracle loads it
+        ridx = getattr(ref, kind + sfx)(X, **{labkw: labels}, build_params=ref.BuildParams(24, 48, 1.0, cache), **kw)
+    oidx = getattr(oracle, kind + sfx)(X, **{labkw: labels}, build_params=oracle.BuildParams(24, 48, 1.0, cache), **kw)
+    integer_data = gen is sift_like
+    methods = ["optimized_postfilter", "fenwick", "three_split"] if kind.endswith("RangeFilterTreeIndex") else [None]
+    for p in (-5, -3, -1, 0):
+        W = windows(labels, nq, p, 40 + p)
+        for method in methods:
+            for beam, mult in [(10, 1), (40, 2)]:
+                a = (Q, W, nq) + ((method,) if method else ())
+                with quiet_stdout():
+                    ri, rd = ridx.batch_search(*a, ref.QueryParams(10, beam, 1.35, 10**7, 10**4, mult, 10000, None, False))
+                oi, od = oidx.batch_search(*a, oracle.QueryParams(10, beam, 1.35, 10**7, 10**4, mult, 10000, None, False))
+                assert np.array_equal(rd, od), (kind, p, method, beam, mult)
+                if not integer_data or (kind == "VamanaRangeFilterTreeIndex" and method == "optimized_postfilter") \
+                        or kind in ("SuperOptimizedPostfilterTreeIndex", "PostfilterVamanaIndex"):
+                    assert np.array_equal(ri, oi), (kind, p, method, beam, mult)

@@ -73,6 +73,8 @@ struct RouteArgs {
   float ratio;
   Task *tasks;       // [nq]
   int32_t *graph_list, *graph_count;
+  int32_t *heavy_list, *heavy_count;  // graph tasks expected to need several doublings
+  int32_t heavy_ratio;                // partition size / window size at or above which a task is heavy
   int32_t *brute_list, *brute_count;
   Counters *ctr;
 };
@@ -84,31 +86,35 @@ struct SearchArgs {
   const Task *tasks;
   const int32_t *list;
   const int32_t *list_count;
+  const int32_t *heavy_list;   // served before `list` (may be null)
+  const int32_t *heavy_count;
   int32_t *cursor;
-  int32_t B;     // beam of this round
-  int32_t bits;  // log2 of the seen-filter size (beamSearch.h:66)
+  int32_t B;             // first beam of every task of this launch
   int32_t k;
   int64_t limit;
   int32_t degree_limit;
-  int32_t is_final;      // final_beam_multiply re-search: always done afterwards
-  int32_t can_double;    // 2*B < postfiltering_max_beam
-  int32_t wants_final;   // final beam > B  (postfilter_vamana.h:173-181)
-  int32_t *next_list, *next_count;
-  int32_t *final_list, *final_count;
+  int32_t mult;          // final_beam_multiply
+  int32_t max_beam;      // postfiltering_max_beam
+  int32_t cap_inkernel;  // largest beam this launch may run; beyond it tasks leave via next/final lists
+  int32_t pool_bytes;    // per-wave LDS pool for beam + seen-filter
+  int32_t is_final;      // this launch is a final re-search: one search, then done
+  int32_t *next_list, *next_count;                 // tasks whose next doubling exceeds cap_inkernel
+  int32_t *final_list, *final_beam, *final_count;  // tasks whose final re-search beam exceeds cap_inkernel
   unsigned long long *out_key;  // [ntasks][k]  (fkey(dist) << 32 | sorted id)
   int32_t *out_cnt;             // [ntasks]
-  int32_t *g_table;             // per wave slot seen-filter when it does not fit the LDS
-  unsigned long long *g_beam;   // per wave slot beam when it does not fit the LDS
+  int32_t *g_table;             // per wave slot seen-filter, 4 << g_table_bits bytes each (or null)
+  int32_t g_table_bits;
+  unsigned long long *g_beam;   // per wave slot beam, g_beam_cap entries each (or null)
   int64_t g_beam_cap;
   Counters *ctr;
-  // raw mode (wann_raw_beam_search): dump the whole beam instead of the filtered top-k
+  // raw mode (wann_raw_beam_search): one search at beam B, dump the whole beam
   int32_t raw;
   int32_t *raw_ids;
   float *raw_dists;
   int32_t *raw_sizes;
   long long *raw_hops, *raw_cmps;
   const long long *raw_qids;  // raw mode: Point::id() of each query
-  unsigned int *trace;        // debug: per wave slot progress marker in host-visible memory (or null)
+  unsigned long long *prof;   // dev tool: 5 per-phase cycle counters (or null)
 };
 
 struct BruteArgs {
@@ -140,19 +146,18 @@ struct FinalizeArgs {
 // launchers implemented in wann_kernels.hip (all asynchronous on `stream`)
 struct LaunchCfg {
   int blocks;
-  int lds_table;  // 1: seen-filter in LDS
-  int lds_beam;   // 1: beam in LDS
 };
 int launch_route(const RouteArgs &a, void *stream);
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);
 int launch_brute(const BruteArgs &a, int blocks, void *stream);
 int launch_finalize(const FinalizeArgs &a, void *stream);
-// how many bytes of LDS one wave of k_search needs for beam B / table bits / stride
-int search_lds_bytes_per_wave(int B, int bits, int stride, int lds_table, int lds_beam);
+// bytes of LDS one wave of k_search needs: common scratch + the beam / seen-filter pool
+int search_lds_bytes_per_wave(int stride, int pool_bytes);
 const char *launch_last_error();
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxLdsBeam = 2048;  // beams up to this size live in the LDS (16 KiB per wave)
-constexpr int kMaxLdsBits = 12;    // seen-filters up to 2^12 entries live in the LDS (16 KiB per wave)
+constexpr int kMaxLdsBits = 12;       // build kernels: seen-filters up to 2^12 entries live in the LDS
+constexpr int kSearchPoolBytes = 10240;  // k_search per-wave LDS pool: beam <= 1280 entries, filter <= 2^11
+constexpr int kInKernelBeamCap = 1280;   // largest beam the first (in-kernel doubling) launch runs
 
 }  // namespace wann

@@ -60,12 +60,12 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
   DevBuf<Task> tasks;
-  DevBuf<int32_t> list_a, list_b, list_final, list_brute, ints, out_cnt, g_table;
+  DevBuf<int32_t> list_a, list_b, list_final, final_beam, list_heavy, list_brute, ints, out_cnt, g_table;
   DevBuf<unsigned long long> out_key, g_beam;
   DevBuf<Counters> ctr;
   DevBuf<float> q_stage, r_stage, dist_stage;
@@ -83,6 +83,8 @@ struct Workspace {
     list_a.ensure(nq);
     list_b.ensure(nq);
     list_final.ensure(nq);
+    final_beam.ensure(nq);
+    list_heavy.ensure(nq);
     list_brute.ensure(nq);
     ints.ensure(kInts);
     out_cnt.ensure(nq);
@@ -238,26 +240,31 @@ void upload_index(wann_index &I) {
 
 struct RoundCfg {
   LaunchCfg lc;
-  int bits;
   int slots;
+  int table_bits;    // per-slot global seen-filter of 4 << table_bits bytes (0 = none needed)
+  int64_t beam_cap;  // per-slot global beam entries (0 = none needed)
 };
 
-RoundCfg config_for(const wann_index &I, int64_t beam, int64_t work_items) {
-  RoundCfg rc;
-  rc.bits = hash_bits(beam);
-  rc.lc.lds_table = rc.bits <= kMaxLdsBits;
-  rc.lc.lds_beam = beam <= kMaxLdsBeam;
-  const int per_wave = search_lds_bytes_per_wave((int)beam, rc.bits, I.view.stride, rc.lc.lds_table, rc.lc.lds_beam);
-  const int per_block = per_wave * kWavesPerBlock;
+// Launch geometry for a k_search launch whose searches run beams in [first_beam, cap].
+RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items) {
+  RoundCfg rc{};
+  const int pool = kSearchPoolBytes;
+  const int per_block = search_lds_bytes_per_wave(I.view.stride, pool) * kWavesPerBlock;
   if (per_block > 160 * 1024) throw std::runtime_error("beam-search LDS footprint exceeds 160 KiB");
-  int blocks_per_cu = std::min(4, (160 * 1024) / per_block);  // <= 16 waves per CU (register budget)
+  // register budget: the L2 kernel holds a whole 512-B row per lane pair in flight (2 waves/SIMD)
+  int blocks_per_cu = std::min(I.view.metric == 1 ? 4 : 2, (160 * 1024) / per_block);
   blocks_per_cu = std::max(1, blocks_per_cu);
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
-  if (!rc.lc.lds_table) {  // bound the global seen-filter scratch to ~8 GiB
-    int64_t per_slot = (int64_t)4 << rc.bits;
-    int64_t max_slots = std::max<int64_t>(kWavesPerBlock, ((int64_t)8 << 30) / per_slot);
+  const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
+  const int cap_bits = hash_bits(cap);
+  if (cap_bytes + ((int64_t)4 << cap_bits) > pool) {  // some beam of the range keeps its filter in global memory
+    rc.table_bits = cap_bits;
+    int64_t per_slot = (int64_t)4 << cap_bits;
+    int64_t max_slots = std::max<int64_t>(kWavesPerBlock, ((int64_t)16 << 30) / per_slot);
     blocks = std::min(blocks, max_slots / kWavesPerBlock);
   }
+  if (cap_bytes > pool) rc.beam_cap = (cap + 1) & ~(int64_t)1;
+  (void)first_beam;
   blocks = std::min<int64_t>(blocks, (work_items + kWavesPerBlock - 1) / kWavesPerBlock);
   rc.lc.blocks = (int)std::max<int64_t>(blocks, 1);
   rc.slots = rc.lc.blocks * kWavesPerBlock;
@@ -298,6 +305,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.tasks = W.tasks.p;
   ra.graph_list = W.list_a.p;
   ra.graph_count = W.ints.p + I_GRAPH_COUNT;
+  ra.heavy_list = W.list_heavy.p;
+  ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
+  ra.heavy_ratio = 8;
   ra.brute_list = W.list_brute.p;
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
   ra.ctr = W.ctr.p;
@@ -323,71 +333,108 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   int rounds = 0, nev = 2;
   std::vector<std::pair<int, int>> timed;  // event index pairs around search launches
   if (I.H.vamana_leaves && qp.beam_width < qp.postfiltering_max_beam) {
-    int64_t b = qp.beam_width;
-    int32_t *cur_list = W.list_a.p, *nxt_list = W.list_b.p;
-    int32_t *cur_count = W.ints.p + I_GRAPH_COUNT;
-    int64_t work = nq;
-    for (int r = 0; r < kMaxRounds; r++) {
-      const int64_t fb = std::min<int64_t>(b * qp.final_beam_multiply, qp.postfiltering_max_beam);
-      SearchArgs sa{};
-      sa.ix = I.view;
-      sa.queries = d_queries;
-      sa.qid_base = qid_base;
-      sa.tasks = W.tasks.p;
-      sa.list = cur_list;
-      sa.list_count = cur_count;
-      sa.cursor = W.ints.p + I_CURSOR0 + 2 * r;
-      sa.B = (int32_t)b;
-      sa.k = k;
-      sa.limit = qp.limit;
-      sa.degree_limit = (int32_t)std::min<int64_t>(qp.degree_limit, INT32_MAX);
-      sa.is_final = 0;
-      sa.can_double = (2 * b < qp.postfiltering_max_beam) ? 1 : 0;
-      sa.wants_final = (fb > b) ? 1 : 0;
-      sa.next_list = nxt_list;
-      sa.next_count = W.ints.p + I_NEXT0 + r;
-      sa.final_list = W.list_final.p;
-      sa.final_count = W.ints.p + I_FINAL0 + r;
-      sa.out_key = W.out_key.p;
-      sa.out_cnt = W.out_cnt.p;
-      sa.ctr = W.ctr.p;
-      auto launch = [&](SearchArgs &a, int64_t beam, int64_t items) {
-        RoundCfg rc = config_for(I, beam, items);
-        a.bits = rc.bits;
-        a.B = (int32_t)beam;
-        if (!rc.lc.lds_table) {
-          W.g_table.ensure((size_t)rc.slots << rc.bits);
-          a.g_table = W.g_table.p;
-        }
-        if (!rc.lc.lds_beam) {
-          a.g_beam_cap = (beam + 1) & ~(int64_t)1;
-          W.g_beam.ensure((size_t)rc.slots * a.g_beam_cap);
-          a.g_beam = W.g_beam.p;
-        }
-        HIP_CHECK(hipEventRecord(W.ev[nev], st));
-        if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
-        HIP_CHECK(hipEventRecord(W.ev[nev + 1], st));
-        timed.emplace_back(nev, nev + 1);
-        nev += 2;
-        rounds++;
-      };
-      launch(sa, b, work);
+    SearchArgs sa{};
+    sa.ix = I.view;
+    sa.queries = d_queries;
+    sa.qid_base = qid_base;
+    sa.tasks = W.tasks.p;
+    sa.k = k;
+    sa.limit = qp.limit;
+    sa.degree_limit = (int32_t)std::min<int64_t>(qp.degree_limit, INT32_MAX);
+    sa.mult = (int32_t)std::min<int64_t>(qp.final_beam_multiply, INT32_MAX);
+    sa.max_beam = (int32_t)qp.postfiltering_max_beam;
+    sa.pool_bytes = kSearchPoolBytes;
+    sa.out_key = W.out_key.p;
+    sa.out_cnt = W.out_cnt.p;
+    sa.ctr = W.ctr.p;
+    sa.final_list = W.list_final.p;
+    sa.final_beam = W.final_beam.p;
+    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items) {
+      RoundCfg rc = config_for(I, first_beam, cap, items);
+      a.B = (int32_t)first_beam;
+      a.cap_inkernel = (int32_t)cap;
+      a.g_table = nullptr;
+      a.g_beam = nullptr;
+      if (rc.table_bits) {
+        W.g_table.ensure((size_t)rc.slots << rc.table_bits);
+        a.g_table = W.g_table.p;
+        a.g_table_bits = rc.table_bits;
+      }
+      if (rc.beam_cap) {
+        W.g_beam.ensure((size_t)rc.slots * rc.beam_cap);
+        a.g_beam = W.g_beam.p;
+        a.g_beam_cap = rc.beam_cap;
+      }
+      if (nev + 2 > (int)W.ev.size()) throw std::runtime_error("too many search launches in one batch");
+      HIP_CHECK(hipEventRecord(W.ev[nev], st));
+      if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
+      HIP_CHECK(hipEventRecord(W.ev[nev + 1], st));
+      timed.emplace_back(nev, nev + 1);
+      nev += 2;
+      rounds++;
+    };
+    // launch 1: every task, in-kernel doubling up to kInKernelBeamCap (long tasks first)
+    const int64_t b0 = qp.beam_width;
+    const int64_t cap1 = std::max<int64_t>(kInKernelBeamCap, b0);
+    sa.list = W.list_a.p;
+    sa.list_count = W.ints.p + I_GRAPH_COUNT;
+    sa.heavy_list = W.list_heavy.p;
+    sa.heavy_count = W.ints.p + I_HEAVY_COUNT;
+    sa.cursor = W.ints.p + I_CURSOR0;
+    sa.next_list = W.list_b.p;
+    sa.next_count = W.ints.p + I_NEXT0;
+    sa.final_count = W.ints.p + I_FINAL0;
+    launch(sa, b0, cap1, nq);
+    HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    int next_n = W.h_ints[I_NEXT0];
+    // launch 2 (rare): the tasks that must double beyond the cap finish their loop in huge mode
+    if (next_n > 0) {
+      int64_t nb = b0;
+      while (nb <= cap1) nb *= 2;
+      SearchArgs sb = sa;
+      sb.list = W.list_b.p;
+      sb.list_count = W.ints.p + I_NEXT0;
+      sb.heavy_list = nullptr;
+      sb.heavy_count = nullptr;
+      sb.cursor = W.ints.p + I_CURSOR0 + 1;
+      sb.next_list = W.list_a.p;  // cannot be used: cap = max_beam
+      sb.next_count = W.ints.p + I_NEXT0 + 1;
+      launch(sb, nb, qp.postfiltering_max_beam, next_n);
       HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
-      const int next_n = W.h_ints[I_NEXT0 + r], final_n = W.h_ints[I_FINAL0 + r];
-      if (sa.wants_final && final_n > 0) {
-        SearchArgs fa = sa;
-        fa.list = W.list_final.p;
-        fa.list_count = W.ints.p + I_FINAL0 + r;
-        fa.cursor = W.ints.p + I_CURSOR0 + 2 * r + 1;
-        fa.is_final = 1;
-        launch(fa, fb, final_n);
+    }
+    // final re-searches whose beam exceeded the in-kernel cap, grouped by beam
+    const int final_n = W.h_ints[I_FINAL0];
+    if (final_n > 0) {
+      std::vector<int32_t> fl((size_t)final_n), fbm((size_t)final_n);
+      HIP_CHECK(hipMemcpy(fl.data(), W.list_final.p, (size_t)final_n * 4, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(fbm.data(), W.final_beam.p, (size_t)final_n * 4, hipMemcpyDeviceToHost));
+      std::vector<int32_t> beams(fbm);
+      std::sort(beams.begin(), beams.end());
+      beams.erase(std::unique(beams.begin(), beams.end()), beams.end());
+      int gi = 0;
+      for (int32_t fb : beams) {
+        std::vector<int32_t> grp;
+        for (int i = 0; i < final_n; i++)
+          if (fbm[i] == fb) grp.push_back(fl[i]);
+        const int32_t cnt = (int32_t)grp.size();
+        if (I_CURSOR0 + 2 + gi >= I_NEXT0) throw std::runtime_error("too many final-beam groups");
+        HIP_CHECK(hipMemcpyAsync(W.list_a.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(W.ints.p + I_GRAPH_COUNT, &cnt, 4, hipMemcpyHostToDevice, st));
+        SearchArgs sf = sa;
+        sf.list = W.list_a.p;
+        sf.list_count = W.ints.p + I_GRAPH_COUNT;
+        sf.heavy_list = nullptr;
+        sf.heavy_count = nullptr;
+        sf.cursor = W.ints.p + I_CURSOR0 + 2 + gi;
+        sf.is_final = 1;
+        sf.next_count = W.ints.p + I_NEXT0 + 2;
+        sf.final_count = W.ints.p + I_FINAL0 + 1;
+        launch(sf, fb, fb, cnt);
+        HIP_CHECK(hipStreamSynchronize(st));  // grp / cnt are reused by the next group
+        gi++;
       }
-      if (!sa.can_double || next_n == 0) break;
-      b *= 2;
-      std::swap(cur_list, nxt_list);
-      cur_count = W.ints.p + I_NEXT0 + r;
-      work = next_n;
     }
   }
 
@@ -695,7 +742,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     I.view.rs = rs;
     I.view.maxdeg = (int32_t)maxdeg;
     I.view.metric = metric;
-    RoundCfg rc = config_for(I, beam, nq);
+    RoundCfg rc = config_for(I, beam, beam, nq);
     DevBuf<int32_t> g_table;
     DevBuf<unsigned long long> g_beam;
     SearchArgs sa{};
@@ -706,7 +753,10 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     sa.list_count = d_ints.p;
     sa.cursor = d_ints.p + 1;
     sa.B = (int32_t)beam;
-    sa.bits = rc.bits;
+    sa.cap_inkernel = (int32_t)beam;
+    sa.max_beam = INT32_MAX;
+    sa.mult = 1;
+    sa.pool_bytes = kSearchPoolBytes;
     sa.k = 1;
     sa.limit = limit;
     sa.degree_limit = (int32_t)std::min<int64_t>(degree_limit, INT32_MAX);
@@ -718,42 +768,31 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     sa.raw_hops = d_hops.p;
     sa.raw_cmps = d_cmps.p;
     sa.raw_qids = d_qids.p;
-    if (!rc.lc.lds_table) {
-      g_table.ensure((size_t)rc.slots << rc.bits);
+    if (rc.table_bits) {
+      g_table.ensure((size_t)rc.slots << rc.table_bits);
       sa.g_table = g_table.p;
+      sa.g_table_bits = rc.table_bits;
     }
-    if (!rc.lc.lds_beam) {
-      sa.g_beam_cap = (beam + 1) & ~(int64_t)1;
+    if (rc.beam_cap) {
+      sa.g_beam_cap = rc.beam_cap;
       g_beam.ensure((size_t)rc.slots * sa.g_beam_cap);
       sa.g_beam = g_beam.p;
     }
-    const bool dbg = getenv("WANN_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[wann] raw launch: blocks=%d bits=%d lds_table=%d lds_beam=%d B=%d nq=%ld\n", rc.lc.blocks, rc.bits, rc.lc.lds_table, rc.lc.lds_beam, (int)beam, (long)nq);
-    unsigned int *trace = nullptr;
-    if (dbg) {
-      HIP_CHECK(hipHostMalloc((void **)&trace, rc.slots * sizeof(unsigned int)));
-      memset(trace, 0, rc.slots * sizeof(unsigned int));
-      sa.trace = trace;
+    DevBuf<unsigned long long> d_prof;
+    const bool prof = getenv("WANN_PROFILE_PHASES") != nullptr;
+    if (prof) {
+      d_prof.ensure(8);
+      HIP_CHECK(hipMemset(d_prof.p, 0, 8 * sizeof(unsigned long long)));
+      sa.prof = d_prof.p;
     }
     if (launch_search(sa, rc.lc, nullptr)) throw HipError(std::string("k_search: ") + launch_last_error());
-    if (dbg) {
-      fprintf(stderr, "[wann] launched, polling\n");
-      for (int it = 0; it < 100; it++) {
-        hipError_t q = hipStreamQuery(nullptr);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) throw HipError(std::string("stream query: ") + hipGetErrorString(q));
-        usleep(100000);
-        if (it == 99) {
-          fprintf(stderr, "[wann] kernel did not finish in 10 s; trace:");
-          for (int s = 0; s < rc.slots && s < 16; s++) fprintf(stderr, " %x", trace[s]);
-          fprintf(stderr, "\n");
-          fflush(stderr);
-          _exit(3);
-        }
-      }
-    }
     HIP_CHECK(hipDeviceSynchronize());
-    if (dbg) fprintf(stderr, "[wann] synced\n");
+    if (prof) {
+      unsigned long long h[8];
+      HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof h, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[wann phases] beam=%ld nq=%ld cycles: row %llu filter %llu dist %llu merge %llu next %llu\n", (long)beam,
+              (long)nq, h[0], h[1], h[2], h[3], h[4]);
+    }
     HIP_CHECK(hipMemcpy(out_ids, d_rid.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_dists, d_rd.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_sizes, d_rsz.p, (size_t)nq * 4, hipMemcpyDeviceToHost));

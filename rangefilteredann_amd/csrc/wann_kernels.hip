@@ -23,103 +23,141 @@
 namespace wann {
 
 // --------------------------------------------------------------------------------------------
-// k_search
+// k_search: one wavefront takes a task (query, partition) through the WHOLE post-filter loop of
+// PostfilterVamanaIndex::query (postfilter_vamana.h:141-188): search at beam b, count the in-window
+// beam entries, double b and search again from scratch while fewer than k were found, then the
+// optional final re-search at min(b * final_beam_multiply, max_beam).  Doing the loop inside the
+// wave (instead of one launch per doubling round) keeps the GPU busy while the few queries that
+// need large beams run their long, strictly sequential searches.
+//
+// Per-wave LDS: common scratch + a pool of A.pool_bytes that holds, per search,
+//   small: beam + seen-filter          (4 << bits) + 8 B <= pool
+//   big  : beam only, filter in global (8 B <= pool)
+//   huge : nothing (beam and filter in per-slot global scratch)
+// Beams above A.cap_inkernel leave the kernel through next_list / final_list and are handled by
+// follow-up launches of this same kernel (A.is_round).
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_bytes_per_wave(int B, int bits, int stride, bool lds_table,
-                                                  bool lds_beam) {
-  int bytes = stride * 4;              // query vector
-  bytes = (bytes + 15) & ~15;
-  bytes += 64 * 8;                     // cand_key
-  bytes += 64 * 4;                     // cand_id
-  bytes += 64 * 4;                     // cand_dist
-  if (lds_beam) bytes += ((B + 1) & ~1) * 8;
-  if (lds_table) bytes += 4 << bits;
-  return (bytes + 15) & ~15;
+__device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:66
+  long long sq = beam * beam;
+  int e = (sq <= 1) ? 0 : (64 - __builtin_clzll((unsigned long long)(sq - 1)));  // ceil(log2(beam^2))
+  e -= 2;
+  return e < 10 ? 10 : e;
 }
 
-template <int METRIC, bool TABLE_LDS, bool BEAM_LDS>
+template <int METRIC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const int slot = blockIdx.x * kWavesPerBlock + wib;
-  const int B = A.B;
-  const int bits = A.bits;
-  const int per_wave = lds_bytes_per_wave(B, bits, ix.stride, TABLE_LDS, BEAM_LDS);
-  const WaveLds L = carve_wave_lds(smem + (size_t)wib * per_wave, ix.stride, B, BEAM_LDS);
-  u64 *gbeam = BEAM_LDS ? nullptr : A.g_beam + (size_t)slot * A.g_beam_cap;
-  int32_t *gtable = TABLE_LDS ? nullptr : A.g_table + ((size_t)slot << bits);
-  const int total = *A.list_count;
+  const int per_wave = wave_lds_common_bytes(ix.stride) + A.pool_bytes;
+  unsigned char *base = smem + (size_t)wib * per_wave;
+  u64 *gbeam = A.g_beam ? A.g_beam + (size_t)slot * A.g_beam_cap : nullptr;
+  int32_t *gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
+  const int heavy = A.heavy_count ? *A.heavy_count : 0;
+  const int total = heavy + *A.list_count;
 
   for (;;) {
     const int t = wave_ticket(A.cursor);
     if (t >= total) break;
-    const int ti = A.list[t];
+    const int ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
     const Task task = A.tasks[ti];
     const PartDesc part = ix.parts[task.part];
     const int64_t qrow = task.query;
     const int64_t qid = A.raw ? A.raw_qids[qrow] : (A.qid_base + qrow);
     const int64_t row_off = part.start;
 
-    // stage the query (zero padded)
-    for (int i = lane; i < ix.stride; i += 64) L.qv[i] = (i < ix.d) ? A.queries[qrow * ix.d + i] : 0.f;
-    WAVE_SYNC();
-    int m;
-    long long nvis, ncmp;
-    wave_beam_search<METRIC, TABLE_LDS, BEAM_LDS, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit,
-                                                         A.degree_limit, nullptr, 0, m, nvis, ncmp);
-    auto beam_ld = [&](int i) -> u64 { return BEAM_LDS ? L.lbeam[i] : gbeam[i]; };
-
-    if (lane == 0) {
-      atomicAdd(&A.ctr->beam_searches, 1ull);
-      atomicAdd(&A.ctr->hops, (unsigned long long)nvis);
-      atomicAdd(&A.ctr->dist_cmps, (unsigned long long)ncmp);
-    }
-
-    if (A.raw) {  // dump the whole beam (ids local to the partition)
-      for (int x = lane; x < m; x += 64) {
-        u64 e = beam_ld(x);
-        A.raw_ids[qrow * B + x] = (int)((uint32_t)e >> 1);
-        A.raw_dists[qrow * B + x] = funkey((uint32_t)(e >> 32));
-      }
+    long long b = A.B;
+    bool final_pass = A.is_final != 0;
+    for (;;) {  // postfilter_vamana.h:161-181
+      const int B = (int)b;
+      const int bits = hash_bits_dev(b);
+      const int beam_bytes = ((B + 1) & ~1) * 8;
+      const bool beam_lds = beam_bytes <= A.pool_bytes;
+      const bool table_lds = beam_lds && (beam_bytes + (4 << bits) <= A.pool_bytes);
+      WaveLds L = carve_wave_lds(base, ix.stride, B, beam_lds);
+      // stage the query (zero padded); every search restarts from scratch
+      for (int i = lane; i < ix.stride; i += 64) L.qv[i] = (i < ix.d) ? A.queries[qrow * ix.d + i] : 0.f;
+      WAVE_SYNC();
+      int m;
+      long long nvis, ncmp;
+      if (table_lds)
+        wave_beam_search<METRIC, true, true, false>(ix, part, L, nullptr, nullptr, B, bits, qid, A.limit, A.degree_limit,
+                                                    nullptr, 0, m, nvis, ncmp, A.prof);
+      else if (beam_lds)
+        wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
+                                                     nullptr, 0, m, nvis, ncmp, A.prof);
+      else
+        wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
+                                                      nullptr, 0, m, nvis, ncmp, A.prof);
+      auto beam_ld = [&](int i) -> u64 { return beam_lds ? L.lbeam[i] : gbeam[i]; };
       if (lane == 0) {
-        A.raw_sizes[qrow] = m;
-        A.raw_hops[qrow] = nvis;
-        A.raw_cmps[qrow] = ncmp;
+        atomicAdd(&A.ctr->beam_searches, 1ull);
+        atomicAdd(&A.ctr->hops, (unsigned long long)nvis);
+        atomicAdd(&A.ctr->dist_cmps, (unsigned long long)ncmp);
       }
-      continue;
-    }
-
-    // ---- post filter: keep beam entries whose label lies in [lo,hi], first k of them
-    //      (postfilter_vamana.h:234-251); ids become sorted-order indices (subset[local])
-    int found = 0;
-    long long labs = 0;
-    for (int bx = 0; bx < m && found < A.k; bx += 64) {
-      int x = bx + lane;
-      bool act = x < m;
-      u64 e = act ? beam_ld(x) : 0ull;
-      int lid = (int)((uint32_t)e >> 1);
-      float lab = act ? ix.labels[row_off + lid] : 0.f;
-      bool inw = act && (lab >= task.lo) && (lab <= task.hi);
-      u64 im = ballot64(inw);
-      int idx = found + popc64(im & lanemask_lt());
-      if (inw && idx < A.k)
-        A.out_key[(size_t)ti * A.k + idx] = (e & 0xffffffff00000000ull) | (uint32_t)(row_off + lid);
-      found += popc64(im);
-      labs += (m - bx) < 64 ? (m - bx) : 64;
-    }
-    if (found > A.k) found = A.k;
-    if (lane == 0) {
-      A.out_cnt[ti] = found;
-      atomicAdd(&A.ctr->label_reads, (unsigned long long)labs);
-      if (!A.is_final) {
-        if (found >= A.k) {  // doubling loop ends here (postfilter_vamana.h:161-172)
-          if (A.wants_final) A.final_list[atomicAdd(A.final_count, 1)] = ti;
-        } else if (A.can_double) {
-          A.next_list[atomicAdd(A.next_count, 1)] = ti;
+      if (A.raw) {  // dump the whole beam (ids local to the partition)
+        for (int x = lane; x < m; x += 64) {
+          u64 e = beam_ld(x);
+          A.raw_ids[qrow * B + x] = (int)((uint32_t)e >> 1);
+          A.raw_dists[qrow * B + x] = funkey((uint32_t)(e >> 32));
         }
+        if (lane == 0) {
+          A.raw_sizes[qrow] = m;
+          A.raw_hops[qrow] = nvis;
+          A.raw_cmps[qrow] = ncmp;
+        }
+        break;
       }
+      // ---- post filter: keep beam entries whose label lies in [lo,hi], first k of them
+      //      (postfilter_vamana.h:234-251); ids become sorted-order indices (subset[local])
+      int found = 0;
+      long long labs = 0;
+      for (int bx = 0; bx < m && found < A.k; bx += 64) {
+        int x = bx + lane;
+        bool act = x < m;
+        u64 e = act ? beam_ld(x) : 0ull;
+        int lid = (int)((uint32_t)e >> 1);
+        float lab = act ? ix.labels[row_off + lid] : 0.f;
+        bool inw = act && (lab >= task.lo) && (lab <= task.hi);
+        u64 im = ballot64(inw);
+        int idx = found + popc64(im & lanemask_lt());
+        if (inw && idx < A.k)
+          A.out_key[(size_t)ti * A.k + idx] = (e & 0xffffffff00000000ull) | (uint32_t)(row_off + lid);
+        found += popc64(im);
+        labs += (m - bx) < 64 ? (m - bx) : 64;
+      }
+      if (found > A.k) found = A.k;
+      if (lane == 0) {
+        A.out_cnt[ti] = found;
+        atomicAdd(&A.ctr->label_reads, (unsigned long long)labs);
+      }
+      WAVE_SYNC();
+      if (final_pass) break;
+      if (found >= A.k) {  // doubling loop ends here (postfilter_vamana.h:161-172); final re-search?
+        long long fb = b * A.mult;
+        if (fb > A.max_beam) fb = A.max_beam;
+        if (fb <= b) break;
+        if (fb <= A.cap_inkernel) {
+          b = fb;
+          final_pass = true;
+          continue;
+        }
+        if (lane == 0) {
+          int at = atomicAdd(A.final_count, 1);
+          A.final_list[at] = ti;
+          A.final_beam[at] = (int32_t)fb;
+        }
+        break;
+      }
+      const long long nb = 2 * b;
+      if (nb >= A.max_beam) break;  // cannot double any more: the short result stands
+      if (nb > A.cap_inkernel) {
+        if (lane == 0) A.next_list[atomicAdd(A.next_count, 1)] = ti;
+        break;
+      }
+      b = nb;
     }
   }
 }
@@ -345,6 +383,10 @@ __global__ void k_route(RouteArgs A) {
         if (ix.vamana_leaves) {
           t.mode = beam_ok ? T_GRAPH : T_EMPTY;
           t.part = pidx;
+          // scheduling hint only: a window that is a small fraction of its partition will need
+          // several doublings, i.e. a long sequential search -- start those first
+          const uint64_t psz = (uint64_t)ix.parts[pidx].n;
+          t.flags = (w > 0 && psz / w >= (uint64_t)A.heavy_ratio) ? 1 : 0;
         } else {  // PrefilterIndex leaf on a slice of the sorted order
           const PartDesc pd = ix.parts[pidx];
           int64_t s = prefilter_bound(ix.labels + pd.start, pd.n, lo);
@@ -357,7 +399,10 @@ __global__ void k_route(RouteArgs A) {
     }
   }
   A.tasks[q] = t;
-  if (t.mode == T_GRAPH) A.graph_list[atomicAdd(A.graph_count, 1)] = (int32_t)q;
+  if (t.mode == T_GRAPH) {
+    if (t.flags) A.heavy_list[atomicAdd(A.heavy_count, 1)] = (int32_t)q;
+    else A.graph_list[atomicAdd(A.graph_count, 1)] = (int32_t)q;
+  }
   else if (t.mode == T_BRUTE || t.mode == T_BRUTE_GATHER) A.brute_list[atomicAdd(A.brute_count, 1)] = (int32_t)q;
 }
 
@@ -395,12 +440,8 @@ static int check(hipError_t e) {
   return 0;
 }
 
-int search_lds_bytes_per_wave(int B, int bits, int stride, int lds_table, int lds_beam) {
-  int bytes = (stride * 4 + 15) & ~15;
-  bytes += 64 * 8 + 64 * 4 + 64 * 4;
-  if (lds_beam) bytes += ((B + 1) & ~1) * 8;
-  if (lds_table) bytes += 4 << bits;
-  return (bytes + 15) & ~15;
+int search_lds_bytes_per_wave(int stride, int pool_bytes) {
+  return ((stride * 4 + 15) & ~15) + 64 * 8 + 64 * 4 + 64 * 4 + pool_bytes;
 }
 
 int launch_route(const RouteArgs &a, void *stream) {
@@ -411,29 +452,23 @@ int launch_route(const RouteArgs &a, void *stream) {
   return check(hipGetLastError());
 }
 
-template <int METRIC>
-static int launch_search_m(const SearchArgs &a, const LaunchCfg &cfg, void *stream) {
-  size_t lds = (size_t)search_lds_bytes_per_wave(a.B, a.bits, a.ix.stride, cfg.lds_table, cfg.lds_beam) * kWavesPerBlock;
-  dim3 grid(cfg.blocks), block(64 * kWavesPerBlock);
-  hipStream_t s = (hipStream_t)stream;
-#define WANN_LAUNCH(TL, BL)                                                                     \
-  do {                                                                                          \
-    auto kern = k_search<METRIC, TL, BL>;                                                       \
-    if (lds > 48 * 1024)                                                                        \
-      if (check(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return 1; \
-    hipLaunchKernelGGL(kern, grid, block, lds, s, a);                                           \
-  } while (0)
-  if (cfg.lds_table && cfg.lds_beam) WANN_LAUNCH(true, true);
-  else if (!cfg.lds_table && cfg.lds_beam) WANN_LAUNCH(false, true);
-  else if (cfg.lds_table && !cfg.lds_beam) WANN_LAUNCH(true, false);
-  else WANN_LAUNCH(false, false);
-#undef WANN_LAUNCH
-  return check(hipGetLastError());
-}
-
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream) {
   if (cfg.blocks <= 0) return 0;
-  return a.ix.metric == 1 ? launch_search_m<1>(a, cfg, stream) : launch_search_m<0>(a, cfg, stream);
+  size_t lds = (size_t)search_lds_bytes_per_wave(a.ix.stride, a.pool_bytes) * kWavesPerBlock;
+  dim3 grid(cfg.blocks), block(64 * kWavesPerBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (a.ix.metric == 1) {
+    auto kern = k_search<1>;
+    if (lds > 48 * 1024)
+      if (check(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return 1;
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+  } else {
+    auto kern = k_search<0>;
+    if (lds > 48 * 1024)
+      if (check(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return 1;
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+  }
+  return check(hipGetLastError());
 }
 
 int launch_brute(const BruteArgs &a, int blocks, void *stream) {

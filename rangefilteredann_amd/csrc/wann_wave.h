@@ -101,6 +101,48 @@ __device__ __forceinline__ float l2_pair(const float *__restrict__ prow, const f
   return (((other + a0) + a1) + a2) + a3;   // odd lane: ((((s+l4)+l5)+l6)+l7)
 }
 
+// Same arithmetic with the block count known at compile time: no branches, the row's loads, then the
+// query's LDS reads, are issued back to back (the hot path for d = 128 / 96 / 100 / 64 / 32).
+template <int D8C>
+__device__ __forceinline__ float l2_pair_ct(const float *__restrict__ prow, const float *qv, int h, bool active) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (active) {
+    constexpr bool odd = D8C & 1;
+    float4 buf[D8C];
+#pragma unroll
+    for (int i = 0; i < D8C; i++) {
+      const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
+      buf[i] = *reinterpret_cast<const float4 *>(prow + 8 * b + 4 * h);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < D8C; i0 += 8) {
+      float4 q[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + j;
+        if (i < D8C) {
+          const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
+          q[j] = *reinterpret_cast<const float4 *>(qv + 8 * b + 4 * h);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + j;
+        if (i < D8C) {
+          float t;
+          t = buf[i].x - q[j].x; a0 = fmaf(t, t, a0);
+          t = buf[i].y - q[j].y; a1 = fmaf(t, t, a1);
+          t = buf[i].z - q[j].z; a2 = fmaf(t, t, a2);
+          t = buf[i].w - q[j].w; a3 = fmaf(t, t, a3);
+        }
+      }
+    }
+  }
+  float s = ((a0 + a1) + a2) + a3;
+  float other = __shfl_xor(s, 1);
+  return (((other + a0) + a1) + a2) + a3;
+}
+
 // Negative inner product (mips_point.h:60-66 as compiled): running scalar, products rounded then
 // added in index order for the first 8*floor(d/8) elements, fused for the tail.  One lane per row.
 template <int NB>
@@ -140,6 +182,20 @@ __device__ __forceinline__ float mips_lane(const float *__restrict__ prow, const
   return -r;
 }
 
+// Pull the cache lines of rows ids_lds[first..first+count) towards the L2 without consuming them:
+// one dword per 128-B line, result unused (the loads of the rows that follow then hit the cache
+// instead of paying a second serial HBM round trip).
+__device__ __forceinline__ void wave_touch_rows(const IndexView &ix, const int32_t *ids_lds, int first, int count,
+                                                int64_t row_off) {
+  const int lpr = (ix.stride * 4 + 127) >> 7;  // 128-B lines per row
+  const int total = count * lpr;
+  for (int t = lane_id(); t < total; t += 64) {
+    const int c = first + t / lpr, line = t % lpr;
+    const float *addr = ix.points + (row_off + ids_lds[c]) * (int64_t)ix.stride + line * 32;
+    (void)*reinterpret_cast<const volatile int *>(addr);
+  }
+}
+
 // Distances of `cnt` rows whose (sorted-order) row numbers sit in ids_lds[0..cnt): afterwards lane
 // s < cnt holds the distance of row s.  scratch_lds: 64 floats.
 template <int METRIC>
@@ -151,16 +207,25 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
     bool act = lane < cnt;
     int id = act ? ids_lds[lane] : 0;
     const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
+    wave_touch_rows(ix, ids_lds, 0, cnt, row_off);  // one lane walks a whole row: get all its lines moving first
     return mips_lane<8>(prow, qv, ix.d, act);
   } else {
     const int D8 = (ix.d + 7) >> 3;
     const int h = lane & 1;
+    if (cnt > 32) wave_touch_rows(ix, ids_lds, 32, cnt - 32, row_off);  // second pass: start its misses now
     for (int base = 0; base < cnt; base += 32) {
       int s = base + (lane >> 1);
       bool act = s < cnt;
       int id = act ? ids_lds[s] : 0;
       const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
-      float dist = l2_pair<8>(prow, qv, D8, h, act);
+      float dist;
+      switch (D8) {  // wave-uniform
+        case 16: dist = l2_pair_ct<16>(prow, qv, h, act); break;  // d = 128
+        case 12: dist = l2_pair_ct<12>(prow, qv, h, act); break;  // d = 96
+        case 13: dist = l2_pair_ct<13>(prow, qv, h, act); break;  // d = 100
+        case 8: dist = l2_pair_ct<8>(prow, qv, h, act); break;    // d = 64
+        default: dist = l2_pair<16>(prow, qv, D8, h, act); break;
+      }
       if (act && h) scratch_lds[s] = dist;
     }
     WAVE_SYNC();
@@ -292,7 +357,8 @@ template <int METRIC, bool TABLE_LDS, bool BEAM_LDS, bool COLLECT>
 __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const PartDesc &part, const WaveLds &L,
                                                  u64 *gbeam, int32_t *gtable, int B, int bits, int64_t qid,
                                                  int64_t limit, int degree_limit, u64 *vis, int vis_cap,
-                                                 int &m_out, long long &nvis_out, long long &ncmp_out) {
+                                                 int &m_out, long long &nvis_out, long long &ncmp_out,
+                                                 unsigned long long *prof = nullptr) {
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = part.start;
@@ -317,6 +383,17 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
   if (lane == 0) beam_st(0, ((u64)fkey(d0) << 32));
   WAVE_SYNC();
 
+  // optional per-phase cycle accounting (dev tool: wann_raw_beam_search with a profile buffer)
+  unsigned long long tp = 0, acc[6] = {0, 0, 0, 0, 0, 0};
+#define WANN_PHASE(i)                                    \
+  do {                                                   \
+    if (prof) {                                          \
+      unsigned long long tn = __builtin_readcyclecounter(); \
+      acc[i] += tn - tp;                                 \
+      tp = tn;                                           \
+    }                                                    \
+  } while (0)
+  if (prof) tp = __builtin_readcyclecounter();
   while (p < m && nvis < limit) {
     // ---- visit the closest unvisited beam entry (beamSearch.h:111-117)
     const u64 curkey = beam_ld(p);
@@ -331,6 +408,8 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     int a = -1;
     if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
     bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+    if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WANN_PHASE(0);  // row fetch
 
     // ---- lossy direct-mapped "seen" filter, sequential semantics emulated exactly
     //      (beamSearch.h:68-73,126-131): lane i sees the id left in its slot by the nearest
@@ -362,6 +441,7 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     if (keep) L.cand_id[popc64(kmask & lanemask_lt())] = a;
     WAVE_SYNC();
     ncmp += nk;
+    WANN_PHASE(1);  // seen-filter
 
     // ---- score the kept neighbours (beamSearch.h:135-145)
     float cutoff = 2147483648.0f;  // (float)INT_MAX
@@ -371,11 +451,13 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     WAVE_SYNC();
     const bool pass = (lane < nk) && (dist < cutoff);
     const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);
+    WANN_PHASE(2);  // vector fetch + distances
 
     // ---- sort + set_union + truncate (beamSearch.h:148-157)
     int p0;
     if (BEAM_LDS) m = wave_merge(L.lbeam, m, B, pass, key, L.cand_key, &p0);
     else m = wave_merge(gbeam, m, B, pass, key, L.cand_key, &p0);
+    WANN_PHASE(3);  // sort + merge
 
     // ---- next = first beam entry not yet visited (beamSearch.h:175-178)
     int sp = p < p0 ? p : p0;
@@ -390,7 +472,11 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
       }
       sp += 64;
     }
+    WANN_PHASE(4);  // next-node scan
   }
+#undef WANN_PHASE
+  if (prof && lane == 0)
+    for (int i = 0; i < 5; i++) atomicAdd(&prof[i], acc[i]);
   m_out = m;
   nvis_out = nvis;
   ncmp_out = ncmp;

@@ -1,0 +1,18 @@
+import os, sys, time, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from util import sift_like
+import window_ann as wa
+n, d = 200000, 128
+g = sift_like(n, d, 1234); X = g(n)
+cache = "/tmp/phase_cache/"; os.makedirs(cache, exist_ok=True)
+lab = np.arange(n, dtype=np.float32)
+idx = wa.PostfilterVamanaIndexFloatEuclidian(X, filters=lab, build_params=wa.BuildParams(64, 500, 1.0, cache))
+rows = idx.partition_graph(0, 0, 64)
+for nq in (64, 8192):
+    Q = g(nq); qids = np.arange(nq, dtype=np.int64) + 10**7
+    for beam in (40, 320):
+        os.environ["WANN_PROFILE_PHASES"] = "1"
+        ids, dists, sizes, hops, cmps = wa.raw_beam_search(0, X, rows, 0, Q, qids, beam)
+        os.environ.pop("WANN_PROFILE_PHASES")
+        t0 = time.time(); wa.raw_beam_search(0, X, rows, 0, Q, qids, beam); t1 = time.time() - t0
+        print(f"nq={nq} beam={beam}: hops/search {hops.mean():.1f} cmps/search {cmps.mean():.0f} call {t1*1e3:.1f} ms", flush=True)

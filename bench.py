@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--fraction", type=int, default=-3, help="headline window fraction exponent")
     ap.add_argument("--fractions", default="all", help="'all' = also sweep 2^-16..2^0 (N=1), 'headline' = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
     args = ap.parse_args()
 
@@ -197,7 +198,13 @@ def main():
         return W, Wt, rows, best
 
     # ---- headline fraction: pick the setting, then time K steps
-    W, Wt, rows, best = sweep(args.fraction, 1000 + rank)
+    if args.setting:
+        sb, sm = (int(x) for x in args.setting.split(","))
+        W = make_windows(ls, nq, args.fraction, 1000 + rank)
+        Wt = torch.from_numpy(W).to(dev)
+        rows, best = [], dict(beam=sb, mult=sm, recall=float("nan"), wall_ms=0.0, device_ms=0.0)
+    else:
+        W, Wt, rows, best = sweep(args.fraction, 1000 + rank)
     for r in rows:
         log(f"  2^{args.fraction}: beam {r['beam']:4d} x{r['mult']}  recall {r['recall']:.4f}  {r['wall_ms']:.2f} ms  -> {nq / r['wall_ms'] * 1e3:,.0f} QPS")
     if best is None:

@@ -115,6 +115,7 @@ struct SearchArgs {
   long long *raw_hops, *raw_cmps;
   const long long *raw_qids;  // raw mode: Point::id() of each query
   unsigned long long *prof;   // dev tool: 5 per-phase cycle counters (or null)
+  int32_t force_general;      // dev / test: never take the small-beam register path
 };
 
 struct BruteArgs {

@@ -757,6 +757,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     sa.max_beam = INT32_MAX;
     sa.mult = 1;
     sa.pool_bytes = kSearchPoolBytes;
+    sa.force_general = getenv("WANN_FORCE_GENERAL") ? 1 : 0;
     sa.k = 1;
     sa.limit = limit;
     sa.degree_limit = (int32_t)std::min<int64_t>(degree_limit, INT32_MAX);
@@ -790,8 +791,8 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     if (prof) {
       unsigned long long h[8];
       HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof h, hipMemcpyDeviceToHost));
-      fprintf(stderr, "[wann phases] beam=%ld nq=%ld cycles: row %llu filter %llu dist %llu merge %llu next %llu\n", (long)beam,
-              (long)nq, h[0], h[1], h[2], h[3], h[4]);
+      fprintf(stderr, "[wann phases] beam=%ld nq=%ld cycles: row %llu filter %llu dist %llu merge %llu next %llu | loop %llu passing %llu\n", (long)beam,
+              (long)nq, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
     }
     HIP_CHECK(hipMemcpy(out_ids, d_rid.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_dists, d_rd.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));

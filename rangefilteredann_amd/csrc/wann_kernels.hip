@@ -82,7 +82,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
       WAVE_SYNC();
       int m;
       long long nvis, ncmp;
-      if (table_lds)
+      if (table_lds && B <= 64 && !A.force_general)
+        wave_beam_search_small<METRIC>(ix, part, L, B, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
+      else if (table_lds)
         wave_beam_search<METRIC, true, true, false>(ix, part, L, nullptr, nullptr, B, bits, qid, A.limit, A.degree_limit,
                                                     nullptr, 0, m, nvis, ncmp, A.prof);
       else if (beam_lds)

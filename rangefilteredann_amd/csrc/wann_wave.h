@@ -19,7 +19,7 @@ typedef unsigned long long u64;
   } while (0)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ u64 rdlane64(u64 v, int l) {
@@ -105,42 +105,70 @@ __device__ __forceinline__ float l2_pair(const float *__restrict__ prow, const f
 // query's LDS reads, are issued back to back (the hot path for d = 128 / 96 / 100 / 64 / 32).
 template <int D8C>
 __device__ __forceinline__ float l2_pair_ct(const float *__restrict__ prow, const float *qv, int h, bool active) {
+  // inactive lanes are handed a valid row (node 0 of the partition) and compute a value nobody
+  // reads: no per-load exec-mask branches
+  (void)active;
+  constexpr bool odd = D8C & 1;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (active) {
-    constexpr bool odd = D8C & 1;
-    float4 buf[D8C];
+  float4 buf[D8C];
 #pragma unroll
-    for (int i = 0; i < D8C; i++) {
-      const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
-      buf[i] = *reinterpret_cast<const float4 *>(prow + 8 * b + 4 * h);
-    }
+  for (int i = 0; i < D8C; i++) {
+    const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
+    buf[i] = *reinterpret_cast<const float4 *>(prow + 8 * b + 4 * h);
+  }
 #pragma unroll
-    for (int i0 = 0; i0 < D8C; i0 += 8) {
-      float4 q[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int i = i0 + j;
-        if (i < D8C) {
-          const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
-          q[j] = *reinterpret_cast<const float4 *>(qv + 8 * b + 4 * h);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int i = i0 + j;
-        if (i < D8C) {
-          float t;
-          t = buf[i].x - q[j].x; a0 = fmaf(t, t, a0);
-          t = buf[i].y - q[j].y; a1 = fmaf(t, t, a1);
-          t = buf[i].z - q[j].z; a2 = fmaf(t, t, a2);
-          t = buf[i].w - q[j].w; a3 = fmaf(t, t, a3);
-        }
-      }
-    }
+  for (int i = 0; i < D8C; i++) {
+    const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
+    const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * b + 4 * h);
+    float t;
+    t = buf[i].x - q.x; a0 = fmaf(t, t, a0);
+    t = buf[i].y - q.y; a1 = fmaf(t, t, a1);
+    t = buf[i].z - q.z; a2 = fmaf(t, t, a2);
+    t = buf[i].w - q.w; a3 = fmaf(t, t, a3);
   }
   float s = ((a0 + a1) + a2) + a3;
   float other = __shfl_xor(s, 1);
   return (((other + a0) + a1) + a2) + a3;
+}
+
+// Two candidates per lane pair (s and s + 32) with every block of BOTH rows in flight before the
+// first use: one HBM round trip scores up to 64 candidates.
+template <int D8C>
+__device__ __forceinline__ void l2_pair2_ct(const float *__restrict__ prow0, const float *__restrict__ prow1,
+                                            const float *qv, int h, float &d0, float &d1) {
+  constexpr bool odd = D8C & 1;
+  float4 b0[D8C], b1[D8C];
+#pragma unroll
+  for (int i = 0; i < D8C; i++) {
+    const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
+    b0[i] = *reinterpret_cast<const float4 *>(prow0 + 8 * b + 4 * h);
+  }
+#pragma unroll
+  for (int i = 0; i < D8C; i++) {
+    const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
+    b1[i] = *reinterpret_cast<const float4 *>(prow1 + 8 * b + 4 * h);
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < D8C; i++) {
+    const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
+    const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * b + 4 * h);
+    float t;
+    t = b0[i].x - q.x; a0 = fmaf(t, t, a0);
+    t = b0[i].y - q.y; a1 = fmaf(t, t, a1);
+    t = b0[i].z - q.z; a2 = fmaf(t, t, a2);
+    t = b0[i].w - q.w; a3 = fmaf(t, t, a3);
+    t = b1[i].x - q.x; c0 = fmaf(t, t, c0);
+    t = b1[i].y - q.y; c1 = fmaf(t, t, c1);
+    t = b1[i].z - q.z; c2 = fmaf(t, t, c2);
+    t = b1[i].w - q.w; c3 = fmaf(t, t, c3);
+  }
+  float s = ((a0 + a1) + a2) + a3;
+  float other = __shfl_xor(s, 1);
+  d0 = (((other + a0) + a1) + a2) + a3;
+  s = ((c0 + c1) + c2) + c3;
+  other = __shfl_xor(s, 1);
+  d1 = (((other + c0) + c1) + c2) + c3;
 }
 
 // Negative inner product (mips_point.h:60-66 as compiled): running scalar, products rounded then
@@ -212,21 +240,37 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
   } else {
     const int D8 = (ix.d + 7) >> 3;
     const int h = lane & 1;
-    if (cnt > 32) wave_touch_rows(ix, ids_lds, 32, cnt - 32, row_off);  // second pass: start its misses now
-    for (int base = 0; base < cnt; base += 32) {
-      int s = base + (lane >> 1);
-      bool act = s < cnt;
-      int id = act ? ids_lds[s] : 0;
-      const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
-      float dist;
-      switch (D8) {  // wave-uniform
-        case 16: dist = l2_pair_ct<16>(prow, qv, h, act); break;  // d = 128
-        case 12: dist = l2_pair_ct<12>(prow, qv, h, act); break;  // d = 96
-        case 13: dist = l2_pair_ct<13>(prow, qv, h, act); break;  // d = 100
-        case 8: dist = l2_pair_ct<8>(prow, qv, h, act); break;    // d = 64
-        default: dist = l2_pair<16>(prow, qv, D8, h, act); break;
+    if (D8 == 16 || D8 == 12) {  // d = 128 / 96: one round trip for up to 64 candidates
+      const int s0 = lane >> 1, s1 = 32 + (lane >> 1);
+      const bool act0 = s0 < cnt, act1 = s1 < cnt;
+      const int id0 = act0 ? ids_lds[s0] : 0, id1 = act1 ? ids_lds[s1] : 0;
+      const float *p0 = ix.points + (row_off + id0) * (int64_t)ix.stride;
+      const float *p1 = ix.points + (row_off + id1) * (int64_t)ix.stride;
+      float d0, d1;
+      if (cnt > 32) {
+        if (D8 == 16) l2_pair2_ct<16>(p0, p1, qv, h, d0, d1);
+        else l2_pair2_ct<12>(p0, p1, qv, h, d0, d1);
+        if (act1 && h) scratch_lds[s1] = d1;
+      } else {
+        if (D8 == 16) d0 = l2_pair_ct<16>(p0, qv, h, act0);
+        else d0 = l2_pair_ct<12>(p0, qv, h, act0);
       }
-      if (act && h) scratch_lds[s] = dist;
+      if (act0 && h) scratch_lds[s0] = d0;
+    } else {
+      if (cnt > 32) wave_touch_rows(ix, ids_lds, 32, cnt - 32, row_off);  // second pass: start its misses now
+      for (int base = 0; base < cnt; base += 32) {
+        int s = base + (lane >> 1);
+        bool act = s < cnt;
+        int id = act ? ids_lds[s] : 0;
+        const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
+        float dist;
+        switch (D8) {  // wave-uniform
+          case 13: dist = l2_pair_ct<13>(prow, qv, h, act); break;  // d = 100
+          case 8: dist = l2_pair_ct<8>(prow, qv, h, act); break;    // d = 64
+          default: dist = l2_pair<16>(prow, qv, D8, h, act); break;
+        }
+        if (act && h) scratch_lds[s] = dist;
+      }
     }
     WAVE_SYNC();
     float r = (lane < cnt) ? scratch_lds[lane] : 0.f;
@@ -477,6 +521,178 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
 #undef WANN_PHASE
   if (prof && lane == 0)
     for (int i = 0; i < 5; i++) atomicAdd(&prof[i], acc[i]);
+  m_out = m;
+  nvis_out = nvis;
+  ncmp_out = ncmp;
+}
+
+
+// --------------------------------------------------------------------------------------------
+// Small-beam variant (B <= 64, seen-filter in LDS): the beam lives in registers, entry x in lane x,
+// for the whole search.  The union with the scored candidates is computed by ONE loop over the
+// passing candidates in which every lane compares its beam entry and its own candidate with the
+// broadcast candidate key (ballots give the insertion point and the duplicate test as scalars), so
+// there is no binary search and a single LDS round trip per hop (write the merged beam, read it
+// back).  Same results as wave_beam_search (the parity tests run both).
+// --------------------------------------------------------------------------------------------
+template <int METRIC>
+__device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, const PartDesc &part, const WaveLds &L,
+                                                       int B, int64_t qid, int64_t limit, int degree_limit,
+                                                       int &m_out, long long &nvis_out, long long &ncmp_out,
+                                                       unsigned long long *prof = nullptr) {
+  const int lane = lane_id();
+  constexpr int bits = 10;  // max(10, ceil(log2(B*B)) - 2) for B <= 64
+  constexpr uint32_t tmask = (1u << bits) - 1u;
+  constexpr uint32_t TAG = 0x80000000u;
+  const int64_t row_off = part.start;
+  for (int i = lane; i < (1 << bits); i += 64) L.ltable[i] = -1;
+  if (lane == 0) L.cand_id[0] = 0;
+  WAVE_SYNC();
+  float d0 = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, 1, row_off);
+  d0 = __shfl(d0, 0);
+  int m = 1, p = 0;
+  long long nvis = 0, ncmp = 1;
+  u64 e = (lane == 0) ? ((u64)fkey(d0) << 32) : ~0ull;  // beam entry of this lane (lane < m)
+  unsigned long long tp = 0, acc[6] = {0, 0, 0, 0, 0, 0}, nc_total = 0;
+#define WANN_PHASE(i)                                       \
+  do {                                                      \
+    if (prof) {                                             \
+      unsigned long long tn = __builtin_readcyclecounter(); \
+      acc[i] += tn - tp;                                    \
+      tp = tn;                                              \
+    }                                                       \
+  } while (0)
+  if (prof) tp = __builtin_readcyclecounter();
+
+  while (p < m && nvis < limit) {
+    const u64 curkey = rdlane64(e, p);
+    const int cur = (int)((uint32_t)curkey >> 1);
+    if (lane == p) e |= 1ull;
+    nvis++;
+    int a = -1;
+    if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
+    const bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+    if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WANN_PHASE(0);
+
+    // ---- seen-filter.  Fast path: tag every slot with the lane number; if every lane reads its own tag
+    //      back, no two lanes of the row share a slot and the sequential rule is just "old == id".
+    const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
+    int old = -1;
+    if (valid) old = L.ltable[loc];
+    WAVE_SYNC();
+    if (valid) L.ltable[loc] = (int)(TAG | (uint32_t)lane);
+    WAVE_SYNC();
+    int rb = 0;
+    if (valid) rb = L.ltable[loc];
+    const bool clash = valid && (rb != (int)(TAG | (uint32_t)lane));
+    bool seen;
+    const bool had_clash = ballot64(clash) != 0;
+    if (!had_clash) {
+      seen = valid && (old == a);
+      WAVE_SYNC();
+      if (valid) L.ltable[loc] = a;
+    } else {  // shared slots (or a node listed twice): exact sequential emulation
+      u64 eq = ballot64(valid);
+      for (int b = 0; b < bits; b++) {
+        const bool bit = (loc >> b) & 1u;
+        const u64 bm = ballot64(valid && bit);
+        eq &= bit ? bm : ~bm;
+      }
+      const u64 lower = eq & lanemask_lt();
+      const u64 higher = (lane == 63) ? 0ull : (eq >> (lane + 1));
+      const int prev_lane = lower ? (63 - __builtin_clzll(lower)) : lane;
+      int prev_val = __shfl(a, prev_lane);
+      if (!lower) prev_val = old;
+      seen = valid && (prev_val == a);
+      WAVE_SYNC();
+      if (valid) L.ltable[loc] = a;               // clears every tag; classes end up holding ...
+      WAVE_SYNC();
+      if (valid && higher == 0) L.ltable[loc] = a;  // ... the id of their last lane
+    }
+    const bool keep = valid && !seen;
+    const u64 kmask = ballot64(keep);
+    const int nk = popc64(kmask);
+    if (keep) L.cand_id[popc64(kmask & lanemask_lt())] = a;
+    WAVE_SYNC();
+    ncmp += nk;
+    WANN_PHASE(1);
+
+    float cutoff = 2147483648.0f;
+    if (m >= B) cutoff = funkey((uint32_t)(rdlane64(e, m - 1) >> 32));
+    const float dist = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, nk, row_off);
+    const int cid = (lane < nk) ? L.cand_id[lane] : 0;
+    WAVE_SYNC();
+    const bool pass = (lane < nk) && (dist < cutoff);
+    const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);
+    WANN_PHASE(2);
+
+    // ---- union (std::set_union multiset rule) with every operand in registers
+    const u64 smask = ballot64(pass);
+    if (smask) {
+      const bool has = lane < m;
+      const u64 ek = e | 1ull, kk = key | 1ull;  // empty lanes hold ~0: never below a candidate
+      int rank = 0, sx = 0, mypos = 0, cp = 0;
+      bool mydup = false;
+      for (u64 mm = smask; mm; mm &= mm - 1) {
+        const int i = ctz64(mm);
+        const u64 ki = rdlane64(kk, i);
+        const bool below = ek < ki;  // my beam entry sorts before candidate i
+        const int pos_i = popc64(ballot64(below));
+        const u64 eqb = ballot64(ek == ki);
+        bool dup_i, before_me;
+        if (!had_clash) {
+          // the row held distinct ids in distinct filter slots, so candidate keys are distinct and
+          // candidate i is a copy only if the beam already holds its key
+          dup_i = eqb != 0;
+          before_me = pass && (ki < kk);
+        } else {  // general multiset rule of std::set_union
+          const int ji = popc64(ballot64(pass && kk == ki) & (((u64)1 << i) - 1));
+          dup_i = ji < popc64(eqb);
+          before_me = pass && (ki < kk || (ki == kk && i < lane));
+        }
+        if (lane == i) {
+          mypos = pos_i;
+          mydup = dup_i;
+        }
+        if (!dup_i) {
+          cp++;
+          rank += before_me ? 1 : 0;
+          sx += (has && !below) ? 1 : 0;
+        }
+      }
+      if (prof) {
+        unsigned long long tn = __builtin_readcyclecounter();
+        acc[5] += tn - tp;  // merge loop only (not reset: phase 3 still covers everything)
+        nc_total += popc64(smask);
+      }
+      if (cp) {
+        if (has) {
+          const int nx = lane + sx;
+          if (nx < B) L.lbeam[nx] = e;
+        }
+        if (pass && !mydup) {
+          const int np = mypos + rank;
+          if (np < B) L.lbeam[np] = key;
+        }
+        WAVE_SYNC();
+        m = (m + cp) < B ? (m + cp) : B;
+        e = (lane < m) ? L.lbeam[lane] : ~0ull;
+        WAVE_SYNC();
+      }
+    }
+    WANN_PHASE(3);
+    const u64 um = ballot64((lane < m) && !(e & 1ull));
+    p = um ? ctz64(um) : m;
+    WANN_PHASE(4);
+  }
+#undef WANN_PHASE
+  if (lane < m) L.lbeam[lane] = e;  // final beam for the caller
+  WAVE_SYNC();
+  if (prof && lane == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(&prof[i], acc[i]);
+    atomicAdd(&prof[6], nc_total);
+  }
   m_out = m;
   nvis_out = nvis;
   ncmp_out = ncmp;

@@ -156,9 +156,8 @@ def main():
     os.makedirs(cache, exist_ok=True)
     bp = wa.BuildParams(R, L, alpha, cache)
     t0 = time.time()
-    if world > 1:  # split the graph build over the ranks through the shared graph cache
-        wa.build_cache_shard(3, 0, X, labels, cutoff, split, 0.5, bp, rank, world, 0)
-        dist.barrier()
+    if world > 1:  # every rank builds its replica on its own GPU (seconds); no shared cache files
+        bp = wa.BuildParams(R, L, alpha, "")
     index = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=cutoff, split_factor=split, build_params=bp)
     build_s = time.time() - t0
     log(f"index ready in {build_s:.1f}s: levels {index.levels()}, {index.device_bytes() / 2**30:.2f} GiB in HBM")

@@ -71,7 +71,9 @@ struct RouteArgs {
   int32_t beam, max_beam;
   int32_t has_ratio;
   float ratio;
-  Task *tasks;       // [nq]
+  Task *tasks;         // [nq * maxt]: query q owns tasks[q*maxt .. q*maxt + qtask_cnt[q])
+  int32_t maxt;        // task slots per query (1 unless the method covers a window with several buckets)
+  int32_t *qtask_cnt;  // [nq]
   int32_t *graph_list, *graph_count;
   int32_t *heavy_list, *heavy_count;  // graph tasks expected to need several doublings
   int32_t heavy_ratio;                // partition size / window size at or above which a task is heavy
@@ -134,6 +136,8 @@ struct BruteArgs {
 struct FinalizeArgs {
   IndexView ix;
   const Task *tasks;
+  int32_t maxt;
+  const int32_t *qtask_cnt;
   const unsigned long long *out_key;
   const int32_t *out_cnt;
   int64_t nq;

@@ -65,7 +65,7 @@ constexpr int kMaxRounds = 30;
 
 struct Workspace {
   DevBuf<Task> tasks;
-  DevBuf<int32_t> list_a, list_b, list_final, final_beam, list_heavy, list_brute, ints, out_cnt, g_table;
+  DevBuf<int32_t> list_a, list_b, list_final, final_beam, list_heavy, list_brute, ints, out_cnt, g_table, qtask_cnt;
   DevBuf<unsigned long long> out_key, g_beam;
   DevBuf<Counters> ctr;
   DevBuf<float> q_stage, r_stage, dist_stage;
@@ -78,17 +78,19 @@ struct Workspace {
     if (h_ctr) (void)hipHostFree(h_ctr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
-  void ensure(int64_t nq, int k) {
-    tasks.ensure(nq);
-    list_a.ensure(nq);
-    list_b.ensure(nq);
-    list_final.ensure(nq);
-    final_beam.ensure(nq);
-    list_heavy.ensure(nq);
-    list_brute.ensure(nq);
+  void ensure(int64_t nq, int k, int maxt) {
+    const size_t nt = (size_t)nq * maxt;
+    tasks.ensure(nt);
+    qtask_cnt.ensure(nq);
+    list_a.ensure(nt);
+    list_b.ensure(nt);
+    list_final.ensure(nt);
+    final_beam.ensure(nt);
+    list_heavy.ensure(nt);
+    list_brute.ensure(nt);
     ints.ensure(kInts);
-    out_cnt.ensure(nq);
-    out_key.ensure((size_t)nq * k);
+    out_cnt.ensure(nt);
+    out_key.ensure(nt * k);
     ctr.ensure(1);
     if (!h_ints) HIP_CHECK(hipHostMalloc((void **)&h_ints, kInts * sizeof(int32_t)));
     if (!h_ctr) HIP_CHECK(hipHostMalloc((void **)&h_ctr, sizeof(Counters)));
@@ -285,7 +287,14 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   HIP_CHECK(hipSetDevice(I.device));
   Workspace &W = I.ws;
   const int k = (int)qp.k;
-  W.ensure(nq, k);
+  const int mcode = method_code(method);
+  const bool tree = I.H.spec.kind == WANN_KIND_TREE_PREFILTER || I.H.spec.kind == WANN_KIND_TREE_VAMANA;
+  // fenwick / three_split cover a window with several buckets (+ two brute-forced ends)
+  // (optimized_postfilter needs one slot unless its tiny-window / ratio fallback reaches the
+  // multi-bucket fenwick cover, which cannot happen for split <= 4 without a ratio: SURVEY.md A.5)
+  const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.H.spec.split_factor <= 4);
+  const int maxt = single ? 1 : 96;
+  W.ensure(nq, k, maxt);
   I.last = wann_counters{};
   if (nq == 0) return;
   HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
@@ -296,7 +305,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.ix = I.view;
   ra.ranges = d_ranges;
   ra.nq = nq;
-  ra.method = method_code(method);
+  ra.method = mcode;
+  ra.maxt = maxt;
+  ra.qtask_cnt = W.qtask_cnt.p;
   ra.k = k;
   ra.beam = (int32_t)std::min<int64_t>(qp.beam_width, INT32_MAX);
   ra.max_beam = (int32_t)std::min<int64_t>(qp.postfiltering_max_beam, INT32_MAX);
@@ -326,7 +337,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     ba.out_key = W.out_key.p;
     ba.out_cnt = W.out_cnt.p;
     ba.ctr = W.ctr.p;
-    int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * 4, (nq + kWavesPerBlock - 1) / kWavesPerBlock);
+    int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * 4, (nq * std::min(maxt, 2) + kWavesPerBlock - 1) / kWavesPerBlock);
     if (launch_brute(ba, blocks, st)) throw HipError(std::string("k_brute: ") + launch_last_error());
   }
 
@@ -384,7 +395,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.next_list = W.list_b.p;
     sa.next_count = W.ints.p + I_NEXT0;
     sa.final_count = W.ints.p + I_FINAL0;
-    launch(sa, b0, cap1, nq);
+    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8));
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
@@ -441,6 +452,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   FinalizeArgs fa{};
   fa.ix = I.view;
   fa.tasks = W.tasks.p;
+  fa.maxt = maxt;
+  fa.qtask_cnt = W.qtask_cnt.p;
   fa.out_key = W.out_key.p;
   fa.out_cnt = W.out_cnt.p;
   fa.nq = nq;
@@ -473,9 +486,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.label_reads = (int64_t)W.h_ctr->label_reads;
   I.last.rounds = rounds;
   if (W.h_ctr->unsupported)
-    throw std::runtime_error("query_method needs the multi-bucket fenwick / three_split cover for " +
-                             std::to_string((long long)W.h_ctr->unsupported) +
-                             " queries; not implemented on the device yet");
+    throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
+                             " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");
 }
 
 // Graphs missing from the cache: built on the GPU straight into the adjacency pool (default) or, with

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "wann_device.h"
 #include "wann_wave.h"
 
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
       WAVE_SYNC();
       if (final_pass) break;
       if (found >= A.k) {  // doubling loop ends here (postfilter_vamana.h:161-172); final re-search?
-        long long fb = b * A.mult;
+        long long fb = b * ((task.flags & 2) ? 1 : A.mult);
         if (fb > A.max_beam) fb = A.max_beam;
         if (fb <= b) break;
         if (fb <= A.cap_inkernel) {
@@ -250,181 +252,356 @@ __device__ __forceinline__ int64_t prefilter_bound(const float *fv, int64_t n, f
   return l;
 }
 
-// true when find_largest_ranges_within_query_range (range_filter_tree.h:234-295) yields a centre
-__device__ bool has_centre(const IndexView &ix, uint64_t istart, uint64_t eend) {
+// ---- task emission: a query owns the slots tasks[q*maxt .. q*maxt+maxt) ---------------------------
+struct Emitter {
+  const RouteArgs &A;
+  int64_t q;
+  int n;
+  bool overflow;
+  __device__ Emitter(const RouteArgs &a, int64_t qq) : A(a), q(qq), n(0), overflow(false) {}
+  __device__ void push(const Task &t) {
+    if (t.mode == T_EMPTY) return;
+    if (n >= A.maxt) {
+      overflow = true;
+      return;
+    }
+    const int32_t ti = (int32_t)(q * A.maxt + n);
+    n++;
+    A.tasks[ti] = t;
+    if (t.mode == T_GRAPH) {
+      if (t.flags & 1) A.heavy_list[atomicAdd(A.heavy_count, 1)] = ti;
+      else A.graph_list[atomicAdd(A.graph_count, 1)] = ti;
+    } else {
+      A.brute_list[atomicAdd(A.brute_count, 1)] = ti;
+    }
+  }
+  // SpatialIndex::query on partition pidx for window [lo,hi]: the post-filter loop on a Vamana
+  // leaf (postfilter_vamana.h:141-188), brute force on a PrefilterIndex leaf (prefiltering.h:154-204)
+  __device__ void leaf(int32_t pidx, float lo, float hi, uint64_t w, bool mult_one) {
+    const IndexView &ix = A.ix;
+    Task t;
+    t.query = (int32_t)q;
+    t.part = pidx;
+    t.flags = 0;
+    t.a = t.b = 0;
+    t.lo = lo;
+    t.hi = hi;
+    const PartDesc pd = ix.parts[pidx];
+    if (ix.vamana_leaves) {
+      t.mode = (A.beam < A.max_beam) ? T_GRAPH : T_EMPTY;  // postfilter_vamana.h:161: no search otherwise
+      // scheduling hint only: a window that is a small fraction of its partition needs several
+      // doublings, i.e. a long sequential search -- start those first
+      if (w > 0 && (uint64_t)pd.n / w >= (uint64_t)A.heavy_ratio) t.flags |= 1;
+      if (mult_one) t.flags |= 2;  // three_split centre: final_beam_multiply forced to 1
+    } else {
+      const int64_t s = prefilter_bound(ix.labels + pd.start, pd.n, lo);
+      const int64_t e = prefilter_bound(ix.labels + pd.start, pd.n, hi);
+      t.a = pd.start + s;
+      t.b = pd.start + e;
+      t.mode = (e > s) ? T_BRUTE : T_EMPTY;
+    }
+    push(t);
+  }
+  __device__ void brute(uint64_t a, uint64_t b) {  // rows [a,b) of the sorted order, no label test
+    if (b <= a) return;
+    Task t;
+    t.query = (int32_t)q;
+    t.mode = T_BRUTE;
+    t.part = 0;
+    t.flags = 0;
+    t.a = (int64_t)a;
+    t.b = (int64_t)b;
+    t.lo = t.hi = 0.f;
+    push(t);
+  }
+};
+
+struct Centre {
+  int64_t row, first, last;
+  uint64_t cover_start, cover_end;
+};
+
+__device__ __forceinline__ int64_t bucket_containing(const int64_t *off, int64_t nb, uint64_t index) {
+  int64_t lo = 0, hi = nb;  // largest b with off[b] <= index   (range_filter_tree.h:213-232)
+  while (lo + 1 < hi) {
+    const int64_t mid = (lo + hi) / 2;
+    if ((uint64_t)off[mid] <= index) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// find_largest_ranges_within_query_range (range_filter_tree.h:234-295)
+__device__ bool find_centre(const IndexView &ix, uint64_t istart, uint64_t eend, Centre &c) {
   const uint64_t range_size = eend - istart;
-  int row = -1;
+  int64_t row = -1;
   for (int r = 0; r < ix.nlevels; r++) {
     const int64_t *off = ix.wst_off + ix.wst_ptr[r];
-    uint64_t bsz = (uint64_t)(off[1] - off[0] - 1);
-    if (bsz <= range_size) {
+    if ((uint64_t)(off[1] - off[0] - 1) <= range_size) {
       row = r;
       break;
     }
   }
   if (row < 0) return false;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    const int64_t *off = ix.wst_off + ix.wst_ptr[row];
-    const int64_t nb = ix.level_nb[row];
-    int64_t first = 0;
-    if (istart != 0) {  // bucket containing istart-1, plus one
-      int64_t lo = 0, hi = nb;  // largest b with off[b] <= istart-1
-      while (lo + 1 < hi) {
-        int64_t mid = (lo + hi) / 2;
-        if ((uint64_t)off[mid] <= istart - 1) lo = mid;
-        else hi = mid;
-      }
-      first = lo + 1;
-    }
-    if (first >= nb) return attempt == 0 ? false : false;  // reference would index past the row
-    uint64_t end = (uint64_t)off[first + 1];
-    if (end <= eend) return true;
-    if (attempt == 1) return true;  // second row is taken as is (range_filter_tree.h:268-281)
+  const int64_t *off = ix.wst_off + ix.wst_ptr[row];
+  int64_t nb = ix.level_nb[row];
+  int64_t first = (istart == 0) ? 0 : bucket_containing(off, nb, istart - 1) + 1;
+  if (first >= nb) return false;  // the reference indexes past the row here (out_of_range)
+  uint64_t start = (uint64_t)off[first], end = (uint64_t)off[first + 1];
+  if (end > eend) {
     row += 1;
     if (row >= ix.nlevels) return false;
+    off = ix.wst_off + ix.wst_ptr[row];
+    nb = ix.level_nb[row];
+    first = (istart == 0) ? 0 : bucket_containing(off, nb, istart - 1) + 1;
+    if (first >= nb) return false;
+    start = (uint64_t)off[first];
+    end = (uint64_t)off[first + 1];
   }
+  int64_t last = first + 1;
+  while (last < nb) {
+    const uint64_t next_end = (uint64_t)off[last + 1];
+    if (next_end > eend) break;
+    last++;
+    end = next_end;
+  }
+  c.row = row;
+  c.first = first;
+  c.last = last;
+  c.cover_start = start;
+  c.cover_end = end;
   return true;
+}
+
+// fenwick_tree_search (range_filter_tree.h:297-401)
+__device__ void emit_fenwick(Emitter &E, float lo, float hi, bool mult_one) {
+  const IndexView &ix = E.A.ix;
+  if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;  // check_empty
+  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
+  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
+  const uint64_t w = eend - istart;
+  Centre c;
+  if (!find_centre(ix, istart, eend, c)) {
+    E.brute(istart, eend);
+    return;
+  }
+  for (int64_t b = c.first; b < c.last; b++) E.leaf((int32_t)(ix.level_part0[c.row] + b), lo, hi, w, mult_one);
+  uint64_t cov_s = c.cover_start, cov_e = c.cover_end;
+  int64_t left = c.first, right = c.last - 1;
+  const int64_t B = ix.split;
+  for (int64_t row = c.row + 1; row < ix.nlevels; row++) {
+    const int64_t *off = ix.wst_off + ix.wst_ptr[row];
+    const int64_t nb = ix.level_nb[row];
+    left *= B;
+    right = right * B + B - 1;
+    while (left > 0) {
+      const uint64_t nls = (uint64_t)off[left - 1];
+      if (nls < istart) break;
+      cov_s = nls;
+      left -= 1;
+      E.leaf((int32_t)(ix.level_part0[row] + left), lo, hi, w, mult_one);
+    }
+    while (right < nb - 1) {
+      const uint64_t nre = (uint64_t)off[right + 2];
+      if (nre > eend) break;
+      cov_e = nre;
+      right += 1;
+      E.leaf((int32_t)(ix.level_part0[row] + right), lo, hi, w, mult_one);
+    }
+  }
+  E.brute(istart, cov_s);
+  E.brute(cov_e, eend);
+}
+
+// optimized_postfiltering_search (range_filter_tree.h:403-471)
+__device__ void emit_optimized(Emitter &E, float lo, float hi) {
+  const IndexView &ix = E.A.ix;
+  if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;
+  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
+  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
+  const uint64_t w = eend - istart;
+  if (4 * w < (uint64_t)(int64_t)ix.cutoff) {  // :419-421
+    emit_fenwick(E, lo, hi, false);
+    return;
+  }
+  int64_t row = 0, idx = 0;
+  while (row + 1 < ix.nlevels) {  // :426-451
+    const int64_t nrow = row + 1;
+    const int64_t *off = ix.wst_off + ix.wst_ptr[nrow];
+    int64_t nidx = -1;
+    for (int64_t c = idx * ix.split; c < idx * ix.split + ix.split; c++) {
+      if (c >= ix.level_nb[nrow]) break;
+      if (istart >= (uint64_t)off[c] && eend <= (uint64_t)off[c + 1]) nidx = c;
+    }
+    if (nidx < 0) break;
+    idx = nidx;
+    row = nrow;
+  }
+  if (E.A.has_ratio) {  // :460-466
+    const int64_t *off = ix.wst_off + ix.wst_ptr[row];
+    const float ratio = (float)(uint64_t)(off[idx + 1] - off[idx]) / (float)w;
+    if (ratio > E.A.ratio) {
+      emit_fenwick(E, lo, hi, false);
+      return;
+    }
+  }
+  E.leaf((int32_t)(ix.level_part0[row] + idx), lo, hi, w, false);
+}
+
+// three_split_search (range_filter_tree.h:473-540)
+__device__ void emit_three_split(Emitter &E, float lo, float hi) {
+  const IndexView &ix = E.A.ix;
+  if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;
+  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
+  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
+  Centre c;
+  if (!find_centre(ix, istart, eend, c)) {
+    emit_fenwick(E, lo, hi, true);  // qp_fenwick: final_beam_multiply = 1
+    return;
+  }
+  for (int64_t b = c.first; b < c.last; b++) E.leaf((int32_t)(ix.level_part0[c.row] + b), lo, hi, eend - istart, true);
+  if (c.cover_start - istart > 0) emit_optimized(E, lo, ix.labels[c.cover_start]);
+  if (eend - c.cover_end > 0) emit_optimized(E, ix.labels[c.cover_end], hi);
+}
+
+// super_optimized_postfiltering_search (super_optimized_postfilter_tree.h:187-270)
+__device__ void emit_super(Emitter &E, float lo, float hi) {
+  const IndexView &ix = E.A.ix;
+  if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;
+  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
+  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
+  const uint64_t w = eend - istart;
+  int level;
+  int64_t idx = 0;
+  for (level = ix.nlevels - 1; level >= 0; level--) {
+    if (level == 0) {
+      idx = 0;
+      break;
+    }
+    const uint64_t bsz = (uint64_t)ix.sup_size[level];
+    if (bsz < w) continue;
+    const uint64_t shift = (uint64_t)ix.sup_shift[level];
+    const uint64_t nb = (uint64_t)ix.level_nb[level];
+    uint64_t fp = istart / shift, lp = (eend - 1) / shift;
+    if (fp > nb - 1) fp = nb - 1;
+    if (lp > nb - 1) lp = nb - 1;
+    bool found = false;
+    for (uint64_t tb = fp; tb <= lp; tb++) {
+      uint64_t bs = tb * shift, be = bs + bsz;
+      if (be > (uint64_t)ix.n) be = (uint64_t)ix.n;
+      if (istart >= bs && eend <= be) {
+        idx = (int64_t)tb;
+        found = true;
+        break;
+      }
+    }
+    if (found) break;
+  }
+  E.leaf((int32_t)(ix.level_part0[level] + idx), lo, hi, w, false);
 }
 
 __global__ void k_route(RouteArgs A) {
   const IndexView &ix = A.ix;
-  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= A.nq) return;
   const float lo = A.ranges[2 * q], hi = A.ranges[2 * q + 1];
-  Task t;
-  t.query = (int32_t)q;
-  t.mode = T_EMPTY;
-  t.part = 0;
-  t.flags = 0;
-  t.a = t.b = 0;
-  t.lo = lo;
-  t.hi = hi;
-  const bool beam_ok = A.beam < A.max_beam;  // postfilter_vamana.h:161: no search at all otherwise
-
-  if (ix.kind == 0) {  // PrefilterIndex: [lb(lo), lb(hi)) over the label argsort
+  Emitter E(A, q);
+  if (ix.kind == 0) {  // PrefilterIndex: [lb(lo), lb(hi)) over the label argsort (prefiltering.h:159-184)
+    Task t;
+    t.query = (int32_t)q;
+    t.part = 0;
+    t.flags = 0;
+    t.lo = lo;
+    t.hi = hi;
     t.a = prefilter_bound(ix.fv_sorted, ix.n, lo);
     t.b = prefilter_bound(ix.fv_sorted, ix.n, hi);
     t.mode = (t.b > t.a) ? T_BRUTE_GATHER : T_EMPTY;
-  } else if (ix.kind == 1) {  // stand-alone PostfilterVamanaIndex: always the one graph
-    t.mode = beam_ok ? T_GRAPH : T_EMPTY;
+    E.push(t);
+  } else if (ix.kind == 1) {  // stand-alone PostfilterVamanaIndex: always the one graph, no window lookup
+    Task t;
+    t.query = (int32_t)q;
     t.part = 0;
+    t.flags = 0;
+    t.a = t.b = 0;
+    t.lo = lo;
+    t.hi = hi;
+    t.mode = (A.beam < A.max_beam) ? T_GRAPH : T_EMPTY;
+    E.push(t);
+  } else if (ix.kind == 4) {
+    emit_super(E, lo, hi);
+  } else if (A.method == M_OPTIMIZED) {
+    emit_optimized(E, lo, hi);
+  } else if (A.method == M_THREE_SPLIT) {
+    emit_three_split(E, lo, hi);
   } else {
-    const bool empty = hi < ix.labels[0] || lo > ix.labels[ix.n - 1];  // range_filter_tree.h:191-203
-    if (!empty) {
-      const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
-      const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
-      const uint64_t w = eend - istart;
-      int level = 0;
-      int64_t idx = 0;
-      bool brute = false, general = false;
-      if (ix.kind == 4) {  // super tree (super_optimized_postfilter_tree.h:204-243)
-        for (level = ix.nlevels - 1; level >= 0; level--) {
-          if (level == 0) {
-            idx = 0;
-            break;
-          }
-          uint64_t bsz = (uint64_t)ix.sup_size[level];
-          if (bsz < w) continue;
-          uint64_t shift = (uint64_t)ix.sup_shift[level];
-          uint64_t nb = (uint64_t)ix.level_nb[level];
-          uint64_t fp = istart / shift, lp = (eend - 1) / shift;
-          if (fp > nb - 1) fp = nb - 1;
-          if (lp > nb - 1) lp = nb - 1;
-          bool found = false;
-          for (uint64_t tb = fp; tb <= lp; tb++) {
-            uint64_t bs = tb * shift, be = bs + bsz;
-            if (be > (uint64_t)ix.n) be = (uint64_t)ix.n;
-            if (istart >= bs && eend <= be) {
-              idx = (int64_t)tb;
-              found = true;
-              break;
-            }
-          }
-          if (found) break;
-        }
-      } else if (A.method != M_OPTIMIZED) {
-        general = true;  // fenwick / three_split: multi-bucket cover
-      } else {
-        if (4 * w < (uint64_t)(int64_t)ix.cutoff) {  // range_filter_tree.h:419-421 -> fenwick
-          if (has_centre(ix, istart, eend)) general = true;
-          else brute = true;
-        } else {
-          int64_t row = 0;
-          idx = 0;
-          while (row + 1 < ix.nlevels) {  // :426-451
-            const int64_t nrow = row + 1;
-            const int64_t *off = ix.wst_off + ix.wst_ptr[nrow];
-            int64_t nidx = -1;
-            for (int64_t c = idx * ix.split; c < idx * ix.split + ix.split; c++) {
-              if (c >= ix.level_nb[nrow]) break;
-              if (istart >= (uint64_t)off[c] && eend <= (uint64_t)off[c + 1]) nidx = c;
-            }
-            if (nidx < 0) break;
-            idx = nidx;
-            row = nrow;
-          }
-          level = (int)row;
-          if (A.has_ratio) {  // :460-466
-            const int64_t *off = ix.wst_off + ix.wst_ptr[row];
-            float ratio = (float)(uint64_t)(off[idx + 1] - off[idx]) / (float)w;
-            if (ratio > A.ratio) {
-              if (has_centre(ix, istart, eend)) general = true;
-              else brute = true;
-            }
-          }
-        }
-      }
-      if (general) {
-        atomicAdd(&A.ctr->unsupported, 1ull);
-      } else if (brute) {
-        t.a = (int64_t)istart;
-        t.b = (int64_t)eend;
-        t.mode = (eend > istart) ? T_BRUTE : T_EMPTY;
-      } else {
-        const int32_t pidx = (int32_t)(ix.level_part0[level] + idx);
-        if (ix.vamana_leaves) {
-          t.mode = beam_ok ? T_GRAPH : T_EMPTY;
-          t.part = pidx;
-          // scheduling hint only: a window that is a small fraction of its partition will need
-          // several doublings, i.e. a long sequential search -- start those first
-          const uint64_t psz = (uint64_t)ix.parts[pidx].n;
-          t.flags = (w > 0 && psz / w >= (uint64_t)A.heavy_ratio) ? 1 : 0;
-        } else {  // PrefilterIndex leaf on a slice of the sorted order
-          const PartDesc pd = ix.parts[pidx];
-          int64_t s = prefilter_bound(ix.labels + pd.start, pd.n, lo);
-          int64_t e = prefilter_bound(ix.labels + pd.start, pd.n, hi);
-          t.a = pd.start + s;
-          t.b = pd.start + e;
-          t.mode = (e > s) ? T_BRUTE : T_EMPTY;
-        }
-      }
-    }
+    emit_fenwick(E, lo, hi, false);
   }
-  A.tasks[q] = t;
-  if (t.mode == T_GRAPH) {
-    if (t.flags) A.heavy_list[atomicAdd(A.heavy_count, 1)] = (int32_t)q;
-    else A.graph_list[atomicAdd(A.graph_count, 1)] = (int32_t)q;
-  }
-  else if (t.mode == T_BRUTE || t.mode == T_BRUTE_GATHER) A.brute_list[atomicAdd(A.brute_count, 1)] = (int32_t)q;
+  A.qtask_cnt[q] = E.n;
+  if (E.overflow) atomicAdd(&A.ctr->unsupported, 1ull);
 }
 
+// One thread per query when every query has at most one task; the multi-task form (fenwick,
+// three_split) merges the per-task top-k lists: concatenate, sort by (dist, id), truncate
+// (range_filter_tree.h:542-549; duplicates are kept like the reference keeps them).
 __global__ void k_finalize(FinalizeArgs A) {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= A.nq) return;
-  const Task t = A.tasks[q];
-  int cnt = (t.mode == T_EMPTY) ? 0 : A.out_cnt[q];
-  const bool decode = A.decode && t.mode != T_BRUTE_GATHER;
+  const int nt = A.qtask_cnt[q];
+  const int64_t ti = q * A.maxt;
+  const int cnt = nt > 0 ? A.out_cnt[ti] : 0;
+  const bool decode = A.decode && (nt == 0 || A.tasks[ti].mode != T_BRUTE_GATHER);
   for (int j = 0; j < A.k; j++) {
     uint32_t id = A.pad_id;
     float dist = 3.402823466e+38f;  // std::numeric_limits<float>::max()
     if (j < cnt) {
-      u64 e = A.out_key[(size_t)q * A.k + j];
+      u64 e = A.out_key[(size_t)ti * A.k + j];
       id = (uint32_t)e;
       if (decode) id = A.ix.decoding[id];
       dist = funkey((uint32_t)(e >> 32));
     }
     A.ids[q * A.k + j] = id;
     A.dists[q * A.k + j] = dist;
+  }
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_finalize_multi(FinalizeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  const int K = A.k;
+  const int per_wave = (64 * 8 + ((K + 1) & ~1) * 8 + 15) & ~15;
+  u64 *cand_key = reinterpret_cast<u64 *>(smem + (size_t)wib * per_wave);
+  u64 *top = cand_key + 64;
+  for (int64_t q = (int64_t)blockIdx.x * kWavesPerBlock + wib; q < A.nq; q += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int nt = A.qtask_cnt[q];
+    int m = 0;
+    for (int t = 0; t < nt; t++) {
+      const int64_t ti = q * A.maxt + t;
+      const int cnt = A.out_cnt[ti];
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const bool have = (c0 + lane) < cnt;
+        u64 e = have ? A.out_key[(size_t)ti * K + c0 + lane] : 0ull;
+        // out_key = fkey(dist) << 32 | sorted id  ->  merge key with the id shifted (bit 0 = flag)
+        u64 key = (e & 0xffffffff00000000ull) | ((u64)(uint32_t)e << 1);
+        bool pass = have;
+        if (pass && m >= K) pass = (key | 1ull) < (top[K - 1] | 1ull);
+        int p0;
+        m = wave_merge<u64 *, false>(top, m, K, pass, key, cand_key, &p0);
+      }
+    }
+    for (int j = lane; j < K; j += 64) {
+      uint32_t id = A.pad_id;
+      float dist = 3.402823466e+38f;
+      if (j < m) {
+        const u64 e = top[j];
+        id = (uint32_t)e >> 1;
+        if (A.decode) id = A.ix.decoding[id];
+        dist = funkey((uint32_t)(e >> 32));
+      }
+      A.ids[q * K + j] = id;
+      A.dists[q * K + j] = dist;
+    }
+    WAVE_SYNC();
   }
 }
 
@@ -486,9 +663,16 @@ int launch_brute(const BruteArgs &a, int blocks, void *stream) {
 
 int launch_finalize(const FinalizeArgs &a, void *stream) {
   if (a.nq == 0) return 0;
-  int threads = 128;
-  int blocks = (int)((a.nq + threads - 1) / threads);
-  hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  if (a.maxt > 1) {
+    int per_wave = (64 * 8 + ((a.k + 1) & ~1) * 8 + 15) & ~15;
+    int blocks = (int)std::min<int64_t>(2048, (a.nq + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(k_finalize_multi, dim3(blocks), dim3(64 * kWavesPerBlock), (size_t)per_wave * kWavesPerBlock,
+                       (hipStream_t)stream, a);
+  } else {
+    int threads = 128;
+    int blocks = (int)((a.nq + threads - 1) / threads);
+    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  }
   return check(hipGetLastError());
 }
 

@@ -287,7 +287,7 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
 // position of the first inserted element (or the old size when nothing was inserted).
 // cand_key: 64 u64 of per-wave LDS scratch.
 // --------------------------------------------------------------------------------------------
-template <typename BeamPtr>
+template <typename BeamPtr, bool DEDUP = true>
 __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass, u64 key,
                                           u64 *cand_key, int *first_pos) {
   const int lane = lane_id();
@@ -322,7 +322,7 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
   // arise when a row lists a node twice -- the reference's builder can append the start point
   // twice -- and the lossy filter lets both through.)
   bool dup = false;
-  if (mine) {
+  if (DEDUP && mine) {
     int j = 0, bx = 0;
     for (int l = lane - 1; l >= 0 && cand_key[l] == ck; l--) j++;
     while (pos + bx < m && ((beam[pos + bx] | 1ull) == (ck | 1ull))) bx++;

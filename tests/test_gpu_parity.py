@@ -59,7 +59,7 @@ def test_raw_beam_search_limits(oracle, wa, gpu):
 # ------------------------------------------------------------------------------------------
 # golden vectors of the real reference, through reference-built graph files
 # ------------------------------------------------------------------------------------------
-SUPPORTED = lambda kind, method: method not in ("fenwick", "three_split")  # noqa: E731
+SUPPORTED = lambda kind, method: True  # noqa: E731  (every query method runs on the device)
 
 
 @pytest.mark.parametrize("name", list(gu.FIXTURES))
@@ -75,7 +75,7 @@ def test_golden_reference_outputs(wa, gpu, tmp_path, name, kind):
             continue
         args = (Q, data["W_" + p], nq) + ((method,) if kind.endswith("RangeFilterTreeIndex") else ())
         ids, dists = idx.batch_search(*args, _qp(wa, beam, mult, K))
-        tie = kind in gu.TIE_AWARE_KINDS or p in ("-7", "edge")
+        tie = kind in gu.TIE_AWARE_KINDS or p in ("-7", "edge") or method in ("fenwick", "three_split")
         ok, why = gu.same_rows(data["ids|" + key], data["dists|" + key], ids, dists, tie)
         assert ok, f"{name} {key}: {why}"
         n += 1
@@ -223,3 +223,31 @@ def test_gpu_builder_matches_host_builder(wa, gpu, tmp_path, monkeypatch, kind, 
     for f in gf:
         a, b = open(gdir + f, "rb").read(), open(hdir + f, "rb").read()
         assert a == b, f"{f}: GPU-built graph differs from the host-built one"
+
+
+# ------------------------------------------------------------------------------------------
+# multi-bucket query methods (fenwick, three_split) and the ratio fallback, against the oracle
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sfx,gen,d,split,cutoff", [("FloatEuclidian", sift_like, 64, 2, 300), ("FloatMips", unit_mixture, 100, 3, 250),
+                                                    ("FloatEuclidian", sift_like, 32, 6, 400)])
+def test_fenwick_and_three_split_match_oracle(oracle, wa, gpu, tmp_path, sfx, gen, d, split, cutoff):
+    n, nq = 5000, 200
+    g = gen(n, d, 41)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 8)
+    cache = str(tmp_path) + "/"
+    kw = dict(cutoff=cutoff, split_factor=split)
+    for kind in ("VamanaRangeFilterTreeIndex", "RangeFilterTreeIndex"):
+        pi = getattr(wa, kind + sfx)(X, labels, build_params=wa.BuildParams(24, 48, 1.0, cache), **kw)
+        oi = getattr(oracle, kind + sfx)(X, labels, build_params=oracle.BuildParams(24, 48, 1.0, cache), **kw)
+        for p in (-9, -6, -4, -2, -1, 0):
+            W = windows(labels, nq, p, seed=70 + p)
+            for method in ("fenwick", "three_split", "smart_combined", "optimized_postfilter"):
+                for beam, mult, ratio in [(10, 1, None), (20, 3, None), (20, 2, 1.5)]:
+                    ids, dists = pi.batch_search(Q, W, nq, method, _qp(wa, beam, mult, ratio=ratio))
+                    eids, edists = oi.batch_search(Q, W, nq, method, _qp(oracle, beam, mult, ratio=ratio))
+                    ok, why = gu.same_rows(eids, edists, ids, dists, True)
+                    assert ok, f"{kind}{sfx} split={split} p={p} {method} beam={beam} x{mult} ratio={ratio}: {why}"
+                    if kind.startswith("Vamana"):
+                        c, oc = pi.counters(), oi.last_counters
+                        assert c["beam_searches"] == oc["searches"] and c["hops"] == oc["hops"], (p, method, beam, mult, ratio)

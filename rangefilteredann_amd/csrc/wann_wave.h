@@ -103,13 +103,24 @@ __device__ __forceinline__ float l2_pair(const float *__restrict__ prow, const f
 
 // Same arithmetic with the block count known at compile time: no branches, the row's loads, then the
 // query's LDS reads, are issued back to back (the hot path for d = 128 / 96 / 100 / 64 / 32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc += (p - q)^2 element-wise with one rounding per element (fma): packed fp32 instructions
+// (v_pk_add_f32 / v_pk_fma_f32) compute exactly what two scalar ops compute.
+__device__ __forceinline__ void sq_acc(f32x2 &lo, f32x2 &hi, const float4 &p, const float4 &q) {
+  f32x2 t0 = f32x2{p.x, p.y} - f32x2{q.x, q.y};
+  f32x2 t1 = f32x2{p.z, p.w} - f32x2{q.z, q.w};
+  lo = __builtin_elementwise_fma(t0, t0, lo);
+  hi = __builtin_elementwise_fma(t1, t1, hi);
+}
+
 template <int D8C>
 __device__ __forceinline__ float l2_pair_ct(const float *__restrict__ prow, const float *qv, int h, bool active) {
   // inactive lanes are handed a valid row (node 0 of the partition) and compute a value nobody
   // reads: no per-load exec-mask branches
   (void)active;
   constexpr bool odd = D8C & 1;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  f32x2 alo = {0.f, 0.f}, ahi = {0.f, 0.f};
   float4 buf[D8C];
 #pragma unroll
   for (int i = 0; i < D8C; i++) {
@@ -120,15 +131,11 @@ __device__ __forceinline__ float l2_pair_ct(const float *__restrict__ prow, cons
   for (int i = 0; i < D8C; i++) {
     const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
     const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * b + 4 * h);
-    float t;
-    t = buf[i].x - q.x; a0 = fmaf(t, t, a0);
-    t = buf[i].y - q.y; a1 = fmaf(t, t, a1);
-    t = buf[i].z - q.z; a2 = fmaf(t, t, a2);
-    t = buf[i].w - q.w; a3 = fmaf(t, t, a3);
+    sq_acc(alo, ahi, buf[i], q);
   }
-  float s = ((a0 + a1) + a2) + a3;
+  float s = ((alo.x + alo.y) + ahi.x) + ahi.y;
   float other = __shfl_xor(s, 1);
-  return (((other + a0) + a1) + a2) + a3;
+  return (((other + alo.x) + alo.y) + ahi.x) + ahi.y;
 }
 
 // Two candidates per lane pair (s and s + 32) with every block of BOTH rows in flight before the
@@ -148,27 +155,20 @@ __device__ __forceinline__ void l2_pair2_ct(const float *__restrict__ prow0, con
     const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
     b1[i] = *reinterpret_cast<const float4 *>(prow1 + 8 * b + 4 * h);
   }
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  f32x2 alo = {0.f, 0.f}, ahi = {0.f, 0.f}, clo = {0.f, 0.f}, chi = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < D8C; i++) {
     const int b = odd ? (i == 0 ? D8C - 1 : i - 1) : i;
     const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * b + 4 * h);
-    float t;
-    t = b0[i].x - q.x; a0 = fmaf(t, t, a0);
-    t = b0[i].y - q.y; a1 = fmaf(t, t, a1);
-    t = b0[i].z - q.z; a2 = fmaf(t, t, a2);
-    t = b0[i].w - q.w; a3 = fmaf(t, t, a3);
-    t = b1[i].x - q.x; c0 = fmaf(t, t, c0);
-    t = b1[i].y - q.y; c1 = fmaf(t, t, c1);
-    t = b1[i].z - q.z; c2 = fmaf(t, t, c2);
-    t = b1[i].w - q.w; c3 = fmaf(t, t, c3);
+    sq_acc(alo, ahi, b0[i], q);
+    sq_acc(clo, chi, b1[i], q);
   }
-  float s = ((a0 + a1) + a2) + a3;
+  float s = ((alo.x + alo.y) + ahi.x) + ahi.y;
   float other = __shfl_xor(s, 1);
-  d0 = (((other + a0) + a1) + a2) + a3;
-  s = ((c0 + c1) + c2) + c3;
+  d0 = (((other + alo.x) + alo.y) + ahi.x) + ahi.y;
+  s = ((clo.x + clo.y) + chi.x) + chi.y;
   other = __shfl_xor(s, 1);
-  d1 = (((other + c0) + c1) + c2) + c3;
+  d1 = (((other + clo.x) + clo.y) + chi.x) + chi.y;
 }
 
 // Negative inner product (mips_point.h:60-66 as compiled): running scalar, products rounded then

@@ -79,6 +79,9 @@ typedef struct {
   int64_t brute_rows;    /* vectors scored by brute-force scans                         */
   int64_t label_reads;   /* labels read by the post filter                              */
   int64_t rounds;        /* kernel launches of the beam-search kernel                   */
+  int64_t spec_searches; /* searches run speculatively beyond the beam the loop stops at */
+  int64_t spec_hops;     /*   (extra work of the concurrent doubling levels; not part of  */
+  int64_t spec_dist_cmps;/*   the reference's operation count)                            */
   double device_ms;      /* HIP-event time of the whole call on its stream              */
   double search_kernel_ms; /* HIP-event time summed over beam-search kernel launches    */
 } wann_counters;

@@ -44,7 +44,9 @@ struct IndexView {
   int32_t d, stride, rs, maxdeg, metric, kind, nlevels, cutoff, split, vamana_leaves;
 };
 
-enum { T_EMPTY = 0, T_GRAPH = 1, T_BRUTE = 2, T_BRUTE_GATHER = 3 };
+enum { T_EMPTY = 0, T_GRAPH = 1, T_BRUTE = 2, T_BRUTE_GATHER = 3, T_PARENT = 4 };
+// Task::flags: 1 = heavy (schedule first), 2 = final_beam_multiply forced to 1, 4 = speculative sub-task
+// (a = beam level, b = parent task index); a T_PARENT task has a = number of sub-tasks, b = first sub-task slot
 enum { M_OPTIMIZED = 0, M_THREE_SPLIT = 1, M_FENWICK = 2 };
 
 // One unit of device work: search partition `part` (T_GRAPH) or scan sorted rows [a,b) (T_BRUTE)
@@ -60,6 +62,9 @@ struct Task {
 
 struct Counters {
   unsigned long long beam_searches, hops, dist_cmps, brute_rows, label_reads, unsupported;
+  // searches run speculatively at beams beyond the one the sequential loop stops at (extra work,
+  // not part of the reference's operation count)
+  unsigned long long spec_searches, spec_hops, spec_dist_cmps;
 };
 
 struct RouteArgs {
@@ -78,6 +83,13 @@ struct RouteArgs {
   int32_t *heavy_list, *heavy_count;  // graph tasks expected to need several doublings
   int32_t heavy_ratio;                // partition size / window size at or above which a task is heavy
   int32_t *brute_list, *brute_count;
+  // speculative doubling: a heavy task spawns one sub-task per beam level b0 << r, r = 0 .. nsub-1,
+  // in the slots [sub_base0, sub_cap); the parent is resolved by whichever sub-task finishes last
+  int32_t spec;         // 0 = off
+  int32_t spec_num;     // spawn levels up to the first beam with beam * w / n_p >= k * spec_num / 8
+  int32_t cap_inkernel;
+  int32_t sub_base0, sub_cap;
+  int32_t *sub_count;   // next free sub-task slot (relative to sub_base0)
   Counters *ctr;
 };
 
@@ -118,6 +130,8 @@ struct SearchArgs {
   const long long *raw_qids;  // raw mode: Point::id() of each query
   unsigned long long *prof;   // dev tool: 5 per-phase cycle counters (or null)
   int32_t force_general;      // dev / test: never take the small-beam register path
+  int32_t *par_done;          // [task slots] finished sub-tasks of a speculating parent
+  long long *sub_hops, *sub_cmps;  // [task slots] work of a sub-task (attributed at resolution)
 };
 
 struct BruteArgs {
@@ -162,7 +176,7 @@ const char *launch_last_error();
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxLdsBits = 12;       // build kernels: seen-filters up to 2^12 entries live in the LDS
-constexpr int kSearchPoolBytes = 10240;  // k_search per-wave LDS pool: beam <= 1280 entries, filter <= 2^11
+constexpr int kSearchPoolBytes = 18432;  // k_search per-wave LDS pool: beam + filter of beams <= 128 (2^12 slots), beam alone <= 2304
 constexpr int kInKernelBeamCap = 1280;   // largest beam the first (in-kernel doubling) launch runs
 
 }  // namespace wann

@@ -60,13 +60,15 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
   DevBuf<Task> tasks;
   DevBuf<int32_t> list_a, list_b, list_final, final_beam, list_heavy, list_brute, ints, out_cnt, g_table, qtask_cnt;
   DevBuf<unsigned long long> out_key, g_beam;
+  DevBuf<long long> sub_hops, sub_cmps;
+  DevBuf<int32_t> par_done;
   DevBuf<Counters> ctr;
   DevBuf<float> q_stage, r_stage, dist_stage;
   DevBuf<uint32_t> id_stage;
@@ -78,8 +80,11 @@ struct Workspace {
     if (h_ctr) (void)hipHostFree(h_ctr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
-  void ensure(int64_t nq, int k, int maxt) {
-    const size_t nt = (size_t)nq * maxt;
+  void ensure(int64_t nq, int k, int maxt, int64_t sub_slots) {
+    const size_t nt = (size_t)nq * maxt + (size_t)sub_slots;
+    par_done.ensure(nt);
+    sub_hops.ensure(nt);
+    sub_cmps.ensure(nt);
     tasks.ensure(nt);
     qtask_cnt.ensure(nq);
     list_a.ensure(nt);
@@ -294,7 +299,10 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   // multi-bucket fenwick cover, which cannot happen for split <= 4 without a ratio: SURVEY.md A.5)
   const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.H.spec.split_factor <= 4);
   const int maxt = single ? 1 : 96;
-  W.ensure(nq, k, maxt);
+  const bool spec = I.H.vamana_leaves && !getenv("WANN_NO_SPEC");
+  const int64_t sub_slots = spec ? std::min<int64_t>(nq * (int64_t)maxt * 4 + 1024, (int64_t)1 << 26) : 0;
+  W.ensure(nq, k, maxt, sub_slots);
+  if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
   I.last = wann_counters{};
   if (nq == 0) return;
   HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
@@ -321,6 +329,12 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.heavy_ratio = 8;
   ra.brute_list = W.list_brute.p;
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
+  ra.spec = spec ? 1 : 0;
+  ra.spec_num = getenv("WANN_SPEC_NUM") ? atoi(getenv("WANN_SPEC_NUM")) : 8;
+  ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp.beam_width);
+  ra.sub_base0 = (int32_t)(nq * maxt);
+  ra.sub_cap = (int32_t)(nq * maxt + sub_slots);
+  ra.sub_count = W.ints.p + I_SUB_COUNT;
   ra.ctr = W.ctr.p;
   if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
 
@@ -360,6 +374,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.ctr = W.ctr.p;
     sa.final_list = W.list_final.p;
     sa.final_beam = W.final_beam.p;
+    sa.par_done = W.par_done.p;
+    sa.sub_hops = W.sub_hops.p;
+    sa.sub_cmps = W.sub_cmps.p;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items) {
       RoundCfg rc = config_for(I, first_beam, cap, items);
       a.B = (int32_t)first_beam;
@@ -395,7 +412,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.next_list = W.list_b.p;
     sa.next_count = W.ints.p + I_NEXT0;
     sa.final_count = W.ints.p + I_FINAL0;
-    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8));
+    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8) + (spec ? nq : 0));
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
@@ -484,6 +501,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.dist_cmps = (int64_t)W.h_ctr->dist_cmps;
   I.last.brute_rows = (int64_t)W.h_ctr->brute_rows;
   I.last.label_reads = (int64_t)W.h_ctr->label_reads;
+  I.last.spec_searches = (int64_t)W.h_ctr->spec_searches;
+  I.last.spec_hops = (int64_t)W.h_ctr->spec_hops;
+  I.last.spec_dist_cmps = (int64_t)W.h_ctr->spec_dist_cmps;
   I.last.rounds = rounds;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
   for (;;) {
     const int t = wave_ticket(A.cursor);
     if (t >= total) break;
-    const int ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
-    const Task task = A.tasks[ti];
+    int ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
+    Task task = A.tasks[ti];
     const PartDesc part = ix.parts[task.part];
     const int64_t qrow = task.query;
     const int64_t qid = A.raw ? A.raw_qids[qrow] : (A.qid_base + qrow);
@@ -72,6 +72,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
 
     long long b = A.B;
     bool final_pass = A.is_final != 0;
+    bool sub = (task.flags & 4) != 0;  // speculative sub-task: ONE search at beam B << level
+    if (sub) b = (long long)A.B << (int)task.a;
     for (;;) {  // postfilter_vamana.h:161-181
       const int B = (int)b;
       const int bits = hash_bits_dev(b);
@@ -85,21 +87,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
       int m;
       long long nvis, ncmp;
       if (table_lds && B <= 64 && !A.force_general)
-        wave_beam_search_small<METRIC>(ix, part, L, B, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
+        wave_beam_search_small<METRIC, 1>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
+      else if (table_lds && B <= 128 && !A.force_general)
+        wave_beam_search_small<METRIC, 2>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
       else if (table_lds)
         wave_beam_search<METRIC, true, true, false>(ix, part, L, nullptr, nullptr, B, bits, qid, A.limit, A.degree_limit,
                                                     nullptr, 0, m, nvis, ncmp, A.prof);
-      else if (beam_lds)
+      else if (beam_lds) {
+        // the part of the pool that the beam leaves free serves as the clash-detection scratch
+        int32_t *mini = nullptr;
+        uint32_t mini_mask = 0;
+        const int free_words = (A.pool_bytes - beam_bytes) >> 2;
+        if (free_words >= 1024 && !A.force_general) {
+          mini = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(L.lbeam) + beam_bytes);
+          mini_mask = (1u << (31 - __builtin_clz((unsigned)free_words))) - 1u;
+        }
         wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
-                                                     nullptr, 0, m, nvis, ncmp, A.prof);
+                                                     nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask);
+      }
       else
         wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
                                                       nullptr, 0, m, nvis, ncmp, A.prof);
       auto beam_ld = [&](int i) -> u64 { return beam_lds ? L.lbeam[i] : gbeam[i]; };
       if (lane == 0) {
-        atomicAdd(&A.ctr->beam_searches, 1ull);
-        atomicAdd(&A.ctr->hops, (unsigned long long)nvis);
-        atomicAdd(&A.ctr->dist_cmps, (unsigned long long)ncmp);
+        if (sub) {  // attributed when the parent is resolved
+          A.sub_hops[ti] = nvis;
+          A.sub_cmps[ti] = ncmp;
+        } else {
+          atomicAdd(&A.ctr->beam_searches, 1ull);
+          atomicAdd(&A.ctr->hops, (unsigned long long)nvis);
+          atomicAdd(&A.ctr->dist_cmps, (unsigned long long)ncmp);
+        }
       }
       if (A.raw) {  // dump the whole beam (ids local to the partition)
         for (int x = lane; x < m; x += 64) {
@@ -138,6 +156,57 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
         atomicAdd(&A.ctr->label_reads, (unsigned long long)labs);
       }
       WAVE_SYNC();
+      if (sub) {
+        // Publish this level, then the LAST sub-task to finish replays the sequential rule over the
+        // levels: the result is that of the first level with >= k in-window entries (or of the last
+        // level), exactly what the doubling loop returns; it then continues as the parent.
+        const int parent = (int)task.b;
+        __threadfence();
+        int old_done = 0;
+        if (lane == 0) old_done = atomicAdd(&A.par_done[parent], 1);
+        old_done = uni(old_done);
+        const Task ptask = A.tasks[parent];
+        const int nsub = (int)ptask.a, sbase = (int)ptask.b;
+        if (old_done + 1 != nsub) break;  // not the last one: take the next ticket
+        __threadfence();
+        int succ = -1;
+        for (int r = 0; r < nsub; r++)
+          if (__hip_atomic_load(&A.out_cnt[sbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.k) {
+            succ = r;
+            break;
+          }
+        const int upto = succ >= 0 ? succ : nsub - 1;
+        if (lane == 0) {
+          unsigned long long h0 = 0, c0 = 0, h1 = 0, c1 = 0;
+          for (int r = 0; r < nsub; r++) {
+            const unsigned long long hh = (unsigned long long)__hip_atomic_load(&A.sub_hops[sbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long cc = (unsigned long long)__hip_atomic_load(&A.sub_cmps[sbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r <= upto) {
+              h0 += hh;
+              c0 += cc;
+            } else {
+              h1 += hh;
+              c1 += cc;
+            }
+          }
+          atomicAdd(&A.ctr->beam_searches, (unsigned long long)(upto + 1));
+          atomicAdd(&A.ctr->hops, h0);
+          atomicAdd(&A.ctr->dist_cmps, c0);
+          atomicAdd(&A.ctr->spec_searches, (unsigned long long)(nsub - 1 - upto));
+          atomicAdd(&A.ctr->spec_hops, h1);
+          atomicAdd(&A.ctr->spec_dist_cmps, c1);
+        }
+        found = __hip_atomic_load(&A.out_cnt[sbase + upto], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = lane; j < found; j += 64)
+          A.out_key[(size_t)parent * A.k + j] =
+              __hip_atomic_load(&A.out_key[(size_t)(sbase + upto) * A.k + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) A.out_cnt[parent] = found;
+        WAVE_SYNC();
+        ti = parent;
+        task = ptask;
+        sub = false;
+        b = (long long)A.B << upto;
+      }
       if (final_pass) break;
       if (found >= A.k) {  // doubling loop ends here (postfilter_vamana.h:161-172); final re-search?
         long long fb = b * ((task.flags & 2) ? 1 : A.mult);
@@ -289,10 +358,48 @@ struct Emitter {
     const PartDesc pd = ix.parts[pidx];
     if (ix.vamana_leaves) {
       t.mode = (A.beam < A.max_beam) ? T_GRAPH : T_EMPTY;  // postfilter_vamana.h:161: no search otherwise
-      // scheduling hint only: a window that is a small fraction of its partition needs several
-      // doublings, i.e. a long sequential search -- start those first
-      if (w > 0 && (uint64_t)pd.n / w >= (uint64_t)A.heavy_ratio) t.flags |= 1;
       if (mult_one) t.flags |= 2;  // three_split centre: final_beam_multiply forced to 1
+      // A window that is a small fraction of its partition needs several doublings, i.e. a long chain of
+      // strictly sequential searches.  Such a task is started first and its doubling levels are searched
+      // CONCURRENTLY by different waves (each level restarts from scratch anyway, postfilter_vamana.h:
+      // 161-172); the sequential rule "first level with >= k in-window results" is applied afterwards.
+      if (t.mode == T_GRAPH && w > 0 && (uint64_t)pd.n / w >= (uint64_t)A.heavy_ratio) {
+        t.flags |= 1;
+        if (A.spec && n < A.maxt) {
+          // expected in-window share of a beam ~ w / partition size: levels up to the first beam with
+          // beam * w / n_p >= k, plus one
+          int nsub = 0;
+          long long bb = A.beam;
+          const unsigned long long need = (unsigned long long)A.k * (uint64_t)pd.n;
+          while (bb < A.max_beam && bb <= A.cap_inkernel && nsub < 12) {
+            nsub++;
+            if ((unsigned long long)bb * w >= need * (unsigned long long)A.spec_num / 8ull) break;
+            bb *= 2;
+          }
+          if (nsub >= 2) {
+            const int base = atomicAdd(A.sub_count, nsub);
+            if (A.sub_base0 + base + nsub <= A.sub_cap) {
+              const int32_t pti = (int32_t)(q * A.maxt + n);
+              Task parent = t;
+              parent.mode = T_PARENT;
+              parent.a = nsub;
+              parent.b = A.sub_base0 + base;
+              A.tasks[pti] = parent;
+              n++;
+              for (int r = nsub - 1; r >= 0; r--) {  // longest search first
+                Task st = t;
+                st.flags |= 4;
+                st.a = r;
+                st.b = pti;
+                const int32_t sti = A.sub_base0 + base + r;
+                A.tasks[sti] = st;
+                A.heavy_list[atomicAdd(A.heavy_count, 1)] = sti;
+              }
+              return;
+            }
+          }
+        }
+      }
     } else {
       const int64_t s = prefilter_bound(ix.labels + pd.start, pd.n, lo);
       const int64_t e = prefilter_bound(ix.labels + pd.start, pd.n, hi);

@@ -402,7 +402,8 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
                                                  u64 *gbeam, int32_t *gtable, int B, int bits, int64_t qid,
                                                  int64_t limit, int degree_limit, u64 *vis, int vis_cap,
                                                  int &m_out, long long &nvis_out, long long &ncmp_out,
-                                                 unsigned long long *prof = nullptr) {
+                                                 unsigned long long *prof = nullptr, int32_t *mini = nullptr,
+                                                 uint32_t mini_mask = 0) {
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = part.start;
@@ -462,22 +463,42 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
     int old = -1;
     if (valid) old = TABLE_LDS ? L.ltable[loc] : gtable[loc];
-    u64 eq = ballot64(valid);
-    for (int b = 0; b < bits; b++) {
-      bool bit = (loc >> b) & 1u;
-      u64 bm = ballot64(valid && bit);
-      eq &= bit ? bm : ~bm;
+    // cheap necessary condition for "two lanes of the row share a filter slot": they would also share a
+    // slot of a small LDS scratch hash.  No clash there => the sequential rule is just "old == id".
+    bool may_clash = true;
+    if (mini) {
+      const uint32_t h = loc & mini_mask;
+      if (valid) mini[h] = lane;
+      WAVE_SYNC();
+      const bool c = valid && (mini[h] != lane);
+      may_clash = ballot64(c) != 0;
+      WAVE_SYNC();
     }
-    const u64 lower = eq & lanemask_lt();
-    const u64 higher = (lane == 63) ? 0ull : (eq >> (lane + 1));
-    int prev_lane = lower ? (63 - __builtin_clzll(lower)) : lane;
-    int prev_val = __shfl(a, prev_lane);
-    if (!lower) prev_val = old;
-    const bool seen = valid && (prev_val == a);
-    WAVE_SYNC();
-    if (valid && higher == 0) {
-      if (TABLE_LDS) L.ltable[loc] = a;
-      else gtable[loc] = a;
+    bool seen;
+    if (!may_clash) {
+      seen = valid && (old == a);
+      if (valid) {
+        if (TABLE_LDS) L.ltable[loc] = a;
+        else gtable[loc] = a;
+      }
+    } else {
+      u64 eq = ballot64(valid);
+      for (int b = 0; b < bits; b++) {
+        bool bit = (loc >> b) & 1u;
+        u64 bm = ballot64(valid && bit);
+        eq &= bit ? bm : ~bm;
+      }
+      const u64 lower = eq & lanemask_lt();
+      const u64 higher = (lane == 63) ? 0ull : (eq >> (lane + 1));
+      int prev_lane = lower ? (63 - __builtin_clzll(lower)) : lane;
+      int prev_val = __shfl(a, prev_lane);
+      if (!lower) prev_val = old;
+      seen = valid && (prev_val == a);
+      WAVE_SYNC();
+      if (valid && higher == 0) {
+        if (TABLE_LDS) L.ltable[loc] = a;
+        else gtable[loc] = a;
+      }
     }
     const bool keep = valid && !seen;
     const u64 kmask = ballot64(keep);
@@ -528,21 +549,21 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
 
 
 // --------------------------------------------------------------------------------------------
-// Small-beam variant (B <= 64, seen-filter in LDS): the beam lives in registers, entry x in lane x,
-// for the whole search.  The union with the scored candidates is computed by ONE loop over the
-// passing candidates in which every lane compares its beam entry and its own candidate with the
-// broadcast candidate key (ballots give the insertion point and the duplicate test as scalars), so
-// there is no binary search and a single LDS round trip per hop (write the merged beam, read it
-// back).  Same results as wave_beam_search (the parity tests run both).
+// Register-resident variant (B <= 64 * NE, seen-filter in LDS): the beam lives in registers for the
+// whole search, entry x in lane x % 64, slot x / 64.  The union with the scored candidates is
+// computed by ONE loop over the passing candidates in which every lane compares its beam entries
+// and its own candidate with the broadcast candidate key (ballots give the insertion point and
+// the duplicate test as scalars), so there is no binary search and a single LDS round trip per
+// hop (write the merged beam, read it back).  Same results as wave_beam_search (the parity tests
+// run both).
 // --------------------------------------------------------------------------------------------
-template <int METRIC>
+template <int METRIC, int NE>
 __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, const PartDesc &part, const WaveLds &L,
-                                                       int B, int64_t qid, int64_t limit, int degree_limit,
+                                                       int B, int bits, int64_t qid, int64_t limit, int degree_limit,
                                                        int &m_out, long long &nvis_out, long long &ncmp_out,
                                                        unsigned long long *prof = nullptr) {
   const int lane = lane_id();
-  constexpr int bits = 10;  // max(10, ceil(log2(B*B)) - 2) for B <= 64
-  constexpr uint32_t tmask = (1u << bits) - 1u;
+  const uint32_t tmask = (1u << bits) - 1u;
   constexpr uint32_t TAG = 0x80000000u;
   const int64_t row_off = part.start;
   for (int i = lane; i < (1 << bits); i += 64) L.ltable[i] = -1;
@@ -552,7 +573,10 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
   d0 = __shfl(d0, 0);
   int m = 1, p = 0;
   long long nvis = 0, ncmp = 1;
-  u64 e = (lane == 0) ? ((u64)fkey(d0) << 32) : ~0ull;  // beam entry of this lane (lane < m)
+  u64 e[NE];  // beam entries of this lane: e[j] is entry 64*j + lane (valid while < m), else ~0
+#pragma unroll
+  for (int j = 0; j < NE; j++) e[j] = ~0ull;
+  if (lane == 0) e[0] = (u64)fkey(d0) << 32;
   unsigned long long tp = 0, acc[6] = {0, 0, 0, 0, 0, 0}, nc_total = 0;
 #define WANN_PHASE(i)                                       \
   do {                                                      \
@@ -563,11 +587,20 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
     }                                                       \
   } while (0)
   if (prof) tp = __builtin_readcyclecounter();
+  auto entry = [&](int x) -> u64 {  // wave-uniform x
+    u64 v = 0;
+#pragma unroll
+    for (int j = 0; j < NE; j++)
+      if ((x >> 6) == j) v = rdlane64(e[j], x & 63);
+    return v;
+  };
 
   while (p < m && nvis < limit) {
-    const u64 curkey = rdlane64(e, p);
+    const u64 curkey = entry(p);
     const int cur = (int)((uint32_t)curkey >> 1);
-    if (lane == p) e |= 1ull;
+#pragma unroll
+    for (int j = 0; j < NE; j++)
+      if (64 * j + lane == p) e[j] |= 1ull;
     nvis++;
     int a = -1;
     if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
@@ -619,7 +652,7 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
     WANN_PHASE(1);
 
     float cutoff = 2147483648.0f;
-    if (m >= B) cutoff = funkey((uint32_t)(rdlane64(e, m - 1) >> 32));
+    if (m >= B) cutoff = funkey((uint32_t)(entry(m - 1) >> 32));
     const float dist = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, nk, row_off);
     const int cid = (lane < nk) ? L.cand_id[lane] : 0;
     WAVE_SYNC();
@@ -630,16 +663,31 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
     // ---- union (std::set_union multiset rule) with every operand in registers
     const u64 smask = ballot64(pass);
     if (smask) {
-      const bool has = lane < m;
-      const u64 ek = e | 1ull, kk = key | 1ull;  // empty lanes hold ~0: never below a candidate
-      int rank = 0, sx = 0, mypos = 0, cp = 0;
+      u64 ek[NE];  // empty slots hold ~0: never below a candidate
+      int sx[NE];
+#pragma unroll
+      for (int j = 0; j < NE; j++) {
+        ek[j] = e[j] | 1ull;
+        sx[j] = 0;
+      }
+      const u64 kk = key | 1ull;
+      int rank = 0, mypos = 0, cp = 0;
       bool mydup = false;
       for (u64 mm = smask; mm; mm &= mm - 1) {
         const int i = ctz64(mm);
         const u64 ki = rdlane64(kk, i);
-        const bool below = ek < ki;  // my beam entry sorts before candidate i
-        const int pos_i = popc64(ballot64(below));
-        const u64 eqb = ballot64(ek == ki);
+        bool below[NE];
+        int pos_i = 0;
+        u64 eqb = 0;
+        int neq = 0;
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+          below[j] = ek[j] < ki;  // my beam entry sorts before candidate i
+          pos_i += popc64(ballot64(below[j]));
+          const u64 eqj = ballot64(ek[j] == ki);
+          eqb |= eqj;
+          neq += popc64(eqj);
+        }
         bool dup_i, before_me;
         if (!had_clash) {
           // the row held distinct ids in distinct filter slots, so candidate keys are distinct and
@@ -648,7 +696,7 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
           before_me = pass && (ki < kk);
         } else {  // general multiset rule of std::set_union
           const int ji = popc64(ballot64(pass && kk == ki) & (((u64)1 << i) - 1));
-          dup_i = ji < popc64(eqb);
+          dup_i = ji < neq;
           before_me = pass && (ki < kk || (ki == kk && i < lane));
         }
         if (lane == i) {
@@ -658,7 +706,8 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
         if (!dup_i) {
           cp++;
           rank += before_me ? 1 : 0;
-          sx += (has && !below) ? 1 : 0;
+#pragma unroll
+          for (int j = 0; j < NE; j++) sx[j] += (!below[j]) ? 1 : 0;  // (empty slots are never written back)
         }
       }
       if (prof) {
@@ -667,9 +716,13 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
         nc_total += popc64(smask);
       }
       if (cp) {
-        if (has) {
-          const int nx = lane + sx;
-          if (nx < B) L.lbeam[nx] = e;
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+          const int x = 64 * j + lane;
+          if (x < m) {
+            const int nx = x + sx[j];
+            if (nx < B) L.lbeam[nx] = e[j];
+          }
         }
         if (pass && !mydup) {
           const int np = mypos + rank;
@@ -677,17 +730,24 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
         }
         WAVE_SYNC();
         m = (m + cp) < B ? (m + cp) : B;
-        e = (lane < m) ? L.lbeam[lane] : ~0ull;
+#pragma unroll
+        for (int j = 0; j < NE; j++) e[j] = (64 * j + lane < m) ? L.lbeam[64 * j + lane] : ~0ull;
         WAVE_SYNC();
       }
     }
     WANN_PHASE(3);
-    const u64 um = ballot64((lane < m) && !(e & 1ull));
-    p = um ? ctz64(um) : m;
+    p = m;
+#pragma unroll
+    for (int j = NE - 1; j >= 0; j--) {
+      const u64 um = ballot64((64 * j + lane < m) && !(e[j] & 1ull));
+      if (um) p = 64 * j + ctz64(um);
+    }
     WANN_PHASE(4);
   }
 #undef WANN_PHASE
-  if (lane < m) L.lbeam[lane] = e;  // final beam for the caller
+#pragma unroll
+  for (int j = 0; j < NE; j++)
+    if (64 * j + lane < m) L.lbeam[64 * j + lane] = e[j];  // final beam for the caller
   WAVE_SYNC();
   if (prof && lane == 0) {
     for (int i = 0; i < 6; i++) atomicAdd(&prof[i], acc[i]);

@@ -137,6 +137,9 @@ class Index {
     d["brute_rows"] = c.brute_rows;
     d["label_reads"] = c.label_reads;
     d["rounds"] = c.rounds;
+    d["spec_searches"] = c.spec_searches;
+    d["spec_hops"] = c.spec_hops;
+    d["spec_dist_cmps"] = c.spec_dist_cmps;
     d["device_ms"] = c.device_ms;
     d["search_kernel_ms"] = c.search_kernel_ms;
     return d;

@@ -10,7 +10,7 @@ idx = wa.PostfilterVamanaIndexFloatEuclidian(X, filters=lab, build_params=wa.Bui
 rows = idx.partition_graph(0, 0, 64)
 for nq in (64, 8192):
     Q = g(nq); qids = np.arange(nq, dtype=np.int64) + 10**7
-    for beam in (40, 320):
+    for beam in (40, 80, 320):
         os.environ["WANN_PROFILE_PHASES"] = "1"
         ids, dists, sizes, hops, cmps = wa.raw_beam_search(0, X, rows, 0, Q, qids, beam)
         os.environ.pop("WANN_PROFILE_PHASES")

@@ -369,6 +369,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.mult = (int32_t)std::min<int64_t>(qp.final_beam_multiply, INT32_MAX);
     sa.max_beam = (int32_t)qp.postfiltering_max_beam;
     sa.pool_bytes = kSearchPoolBytes;
+    sa.force_general = getenv("WANN_FORCE_GENERAL") ? 1 : 0;
     sa.out_key = W.out_key.p;
     sa.out_cnt = W.out_cnt.p;
     sa.ctr = W.ctr.p;

@@ -101,6 +101,7 @@ def test_golden_quirks(wa, gpu, tmp_path, name):
 CASES = [
     ("VamanaRangeFilterTreeIndex", "FloatEuclidian", sift_like, 128, 6000, dict(cutoff=500, split_factor=2)),
     ("VamanaRangeFilterTreeIndex", "FloatMips", unit_mixture, 100, 5000, dict(cutoff=400, split_factor=3)),
+    ("VamanaRangeFilterTreeIndex", "FloatMips", unit_mixture, 96, 6000, dict(cutoff=300, split_factor=4)),  # deep-like 4-WST
     ("SuperOptimizedPostfilterTreeIndex", "FloatMips", unit_mixture, 100, 5000, dict(cutoff=400, split_factor=2, shift_factor=0.5)),
     ("SuperOptimizedPostfilterTreeIndex", "FloatEuclidian", sift_like, 96, 5000, dict(cutoff=300, split_factor=2.5, shift_factor=0.3)),
     ("PostfilterVamanaIndex", "FloatEuclidian", sift_like, 64, 4000, dict()),
@@ -251,3 +252,32 @@ def test_fenwick_and_three_split_match_oracle(oracle, wa, gpu, tmp_path, sfx, ge
                     if kind.startswith("Vamana"):
                         c, oc = pi.counters(), oi.last_counters
                         assert c["beam_searches"] == oc["searches"] and c["hops"] == oc["hops"], (p, method, beam, mult, ratio)
+
+
+def test_scheduling_variants_return_identical_rows(wa, gpu, tmp_path, monkeypatch):
+    """Speculative concurrent doubling, the register-resident beam and the clash-check fast paths are
+    scheduling / layout choices: every combination must return the same rows and the same counters."""
+    n, d, nq = 20000, 128, 600
+    g = sift_like(n, d, 4)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 6)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(32, 100, 1.0, ""))
+    base = {}
+    for env in ({}, {"WANN_NO_SPEC": "1"}, {"WANN_FORCE_GENERAL": "1"}, {"WANN_NO_SPEC": "1", "WANN_FORCE_GENERAL": "1"}):
+        for k_ in ("WANN_NO_SPEC", "WANN_FORCE_GENERAL"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        for p in (-7, -5, -3, 0):
+            W = windows(labels, nq, p, seed=90 + p)
+            for beam, mult in [(10, 1), (40, 2), (80, 1), (100, 1)]:
+                ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+                c = idx.counters()
+                key = (p, beam, mult)
+                cur = (ids.copy(), dists.copy(), c["beam_searches"], c["hops"], c["dist_cmps"])
+                if key not in base:
+                    base[key] = cur
+                else:
+                    b = base[key]
+                    assert np.array_equal(b[0], cur[0]) and np.array_equal(b[1], cur[1]), (env, key)
+                    assert b[2:] == cur[2:], (env, key, b[2:], cur[2:])

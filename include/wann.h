@@ -82,6 +82,7 @@ typedef struct {
   int64_t spec_searches; /* searches run speculatively beyond the beam the loop stops at */
   int64_t spec_hops;     /*   (extra work of the concurrent doubling levels; not part of  */
   int64_t spec_dist_cmps;/*   the reference's operation count)                            */
+  int64_t gemm_queries;  /* PrefilterIndex queries scored through the MFMA GEMM path        */
   double device_ms;      /* HIP-event time of the whole call on its stream              */
   double search_kernel_ms; /* HIP-event time summed over beam-search kernel launches    */
 } wann_counters;

@@ -21,6 +21,7 @@
 #include "../../include/wann.h"
 #include "wann_build.h"
 #include "wann_device.h"
+#include "wann_gemm_device.h"
 #include "wann_gpu_build.h"
 #include "wann_hip_util.h"
 
@@ -123,6 +124,14 @@ struct wann_index {
   IndexView view{};
   int64_t device_bytes = 0;
   Workspace ws;
+  // dense prefilter path (wann_gemm_kernels.hip): |p|^2 per point, computed at first use
+  DevBuf<float> d_pnorm2;
+  DevBuf<unsigned int> d_pnorm2_max;
+  bool have_norms = false;
+  DevBuf<GemmGroup> g_groups;
+  DevBuf<GemmTile> g_tiles;
+  DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_sel_pos, g_sel_cnt;
+  DevBuf<float> g_scores, g_sel_cut;
   hipStream_t own_stream = nullptr;
   wann_counters last{};
   std::mutex mu;
@@ -284,6 +293,94 @@ int method_code(const char *m) {
   return M_FENWICK;  // range_filter_tree.h:76-82: everything else falls through to fenwick
 }
 
+// PrefilterIndex batches in which many queries share a window: score those windows as Q x P^T GEMMs on
+// the matrix cores, keep 32 candidates per query, re-rank them exactly; everything else (and every
+// query whose top-k cannot be proven from the MFMA scores) goes through the exact scan kernel.
+void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, hipStream_t st) {
+  Workspace &W = I.ws;
+  std::vector<Task> tasks((size_t)nq);
+  HIP_CHECK(hipMemcpyAsync(tasks.data(), W.tasks.p, (size_t)nq * sizeof(Task), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  std::vector<int32_t> order;
+  for (int64_t q = 0; q < nq; q++)
+    if (tasks[q].mode == T_BRUTE_GATHER) order.push_back((int32_t)q);
+  std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+    if (tasks[x].a != tasks[y].a) return tasks[x].a < tasks[y].a;
+    if (tasks[x].b != tasks[y].b) return tasks[x].b < tasks[y].b;
+    return x < y;
+  });
+  std::vector<GemmGroup> groups;
+  std::vector<GemmTile> tiles;
+  std::vector<int32_t> gq, tq_group, tq_local, rest;
+  int64_t soff = 0;
+  const int64_t budget = (int64_t)2 << 30;  // floats (8 GiB of scores)
+  for (size_t i = 0; i < order.size();) {
+    size_t j = i;
+    while (j < order.size() && tasks[order[j]].a == tasks[order[i]].a && tasks[order[j]].b == tasks[order[i]].b) j++;
+    const int64_t w = tasks[order[i]].b - tasks[order[i]].a, qc = (int64_t)(j - i);
+    if (qc >= 16 && w >= 64 && k <= kSelect / 2 && soff + qc * w <= budget) {
+      GemmGroup g{tasks[order[i]].a, tasks[order[i]].b, soff, (int32_t)gq.size(), (int32_t)qc};
+      for (int64_t t0 = 0; t0 < qc; t0 += 32) tiles.push_back(GemmTile{(int32_t)groups.size(), (int32_t)t0});
+      for (size_t t = i; t < j; t++) {
+        tq_group.push_back((int32_t)groups.size());
+        tq_local.push_back((int32_t)(t - i));
+        gq.push_back(order[t]);
+      }
+      soff += qc * w;
+      groups.push_back(g);
+    } else {
+      for (size_t t = i; t < j; t++) rest.push_back(order[t]);
+    }
+    i = j;
+  }
+  if (groups.empty()) return;
+  if (!I.have_norms) {
+    I.d_pnorm2.ensure((size_t)I.view.n);
+    I.d_pnorm2_max.ensure(1);
+    HIP_CHECK(hipMemsetAsync(I.d_pnorm2_max.p, 0, sizeof(unsigned int), st));
+    if (launch_point_norms(I.view, I.d_pnorm2.p, I.d_pnorm2_max.p, st)) throw HipError(std::string("k_point_norms: ") + gemm_launch_last_error());
+    I.have_norms = true;
+  }
+  I.g_groups.upload(groups);
+  I.g_tiles.upload(tiles);
+  I.g_gq.upload(gq);
+  I.g_tq_group.upload(tq_group);
+  I.g_tq_local.upload(tq_local);
+  I.g_scores.ensure((size_t)soff);
+  I.g_sel_pos.ensure(gq.size() * kSelect);
+  I.g_sel_cnt.ensure(gq.size());
+  I.g_sel_cut.ensure(gq.size());
+  // the exact scan keeps the ungrouped queries; k_rerank appends the unproven ones to the same list
+  const int32_t nrest = (int32_t)rest.size();
+  if (nrest) HIP_CHECK(hipMemcpyAsync(W.list_brute.p, rest.data(), rest.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(W.ints.p + I_BRUTE_COUNT, &nrest, 4, hipMemcpyHostToDevice, st));
+  GemmArgs ga{};
+  ga.ix = I.view;
+  ga.queries = d_queries;
+  ga.groups = I.g_groups.p;
+  ga.tiles = I.g_tiles.p;
+  ga.ntiles = (int32_t)tiles.size();
+  ga.gq = I.g_gq.p;
+  ga.tq_group = I.g_tq_group.p;
+  ga.tq_local = I.g_tq_local.p;
+  ga.ntq = (int64_t)gq.size();
+  ga.pnorm2 = I.d_pnorm2.p;
+  ga.pnorm2_max_bits = I.d_pnorm2_max.p;
+  ga.scores = I.g_scores.p;
+  ga.sel_pos = I.g_sel_pos.p;
+  ga.sel_cnt = I.g_sel_cnt.p;
+  ga.sel_cut = I.g_sel_cut.p;
+  ga.k = k;
+  ga.out_key = W.out_key.p;
+  ga.out_cnt = W.out_cnt.p;
+  ga.fallback_list = W.list_brute.p;
+  ga.fallback_count = W.ints.p + I_BRUTE_COUNT;
+  if (launch_gemm_scores(ga, st)) throw HipError(std::string("k_gemm_scores: ") + gemm_launch_last_error());
+  if (launch_select_rerank(ga, st)) throw HipError(std::string("k_select/k_rerank: ") + gemm_launch_last_error());
+  HIP_CHECK(hipStreamSynchronize(st));  // host vectors above back the async uploads
+  I.last.gemm_queries = (int64_t)gq.size();
+}
+
 void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int64_t nq, int64_t qid_base,
                const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st) {
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
@@ -337,6 +434,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.sub_count = W.ints.p + I_SUB_COUNT;
   ra.ctr = W.ctr.p;
   if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
+
+  if (I.H.spec.kind == WANN_KIND_PREFILTER && nq >= 32 && !getenv("WANN_NO_GEMM"))
+    dense_prefilter(I, d_queries, nq, k, st);
 
   const bool may_brute = I.H.spec.kind != WANN_KIND_POSTFILTER && I.H.spec.kind != WANN_KIND_SUPER;
   if (may_brute) {

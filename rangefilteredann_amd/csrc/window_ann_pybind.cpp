@@ -140,6 +140,7 @@ class Index {
     d["spec_searches"] = c.spec_searches;
     d["spec_hops"] = c.spec_hops;
     d["spec_dist_cmps"] = c.spec_dist_cmps;
+    d["gemm_queries"] = c.gemm_queries;
     d["device_ms"] = c.device_ms;
     d["search_kernel_ms"] = c.search_kernel_ms;
     return d;

@@ -281,3 +281,46 @@ def test_scheduling_variants_return_identical_rows(wa, gpu, tmp_path, monkeypatc
                     b = base[key]
                     assert np.array_equal(b[0], cur[0]) and np.array_equal(b[1], cur[1]), (env, key)
                     assert b[2:] == cur[2:], (env, key, b[2:], cur[2:])
+
+
+# ------------------------------------------------------------------------------------------
+# dense prefilter path (queries sharing a window -> MFMA GEMM + exact re-rank), adversarial-style data
+# (generate_datasets/generate_advserial_dataset.py:8-69: clusters, labels c - 0.5 + U(0,1), one window per cluster)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,sfx,d", [("mips", "FloatMips", 100), ("l2", "FloatEuclidian", 128), ("l2f", "FloatEuclidian", 96)])
+def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sfx, d):
+    rng = np.random.default_rng(17)
+    nclu, per, qper = 12, 700, 40
+    n = nclu * per
+    if metric == "l2":
+        X = sift_like(n, d, 3)(n)
+        Q = sift_like(n, d, 3)(nclu * qper)
+    else:
+        cent = rng.standard_normal((nclu, d))
+        X = (cent[np.repeat(np.arange(nclu), per)] + 0.3 * rng.standard_normal((n, d)))
+        Q = (cent[np.repeat(np.arange(nclu), qper)] + 0.3 * rng.standard_normal((nclu * qper, d)))
+        X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+        Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    labels = (np.repeat(np.arange(nclu), per) - 0.5 + rng.random(n)).astype(np.float32)
+    perm = rng.permutation(n)
+    X, labels = X[perm], labels[perm]
+    nq = Q.shape[0]
+    W = np.zeros((nq, 2))
+    cl = np.repeat(np.arange(nclu), qper)
+    W[:, 0], W[:, 1] = cl - 0.5, cl + 0.5
+    W[::7] = (2.2, 3.9)       # a second family of shared windows
+    W[5::31, 1] += 1e-3 * np.arange(len(W[5::31]))  # and some unique ones (exact scan)
+    pi = getattr(wa, "PrefilterIndex" + sfx)(X, labels)
+    oi = getattr(oracle, "PrefilterIndex" + sfx)(X, labels)
+    for k in (10, 16):
+        monkeypatch.delenv("WANN_NO_GEMM", raising=False)
+        ids, dists = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
+        c = pi.counters()
+        assert c["gemm_queries"] > nq // 2, c
+        eids, edists = oi.batch_search(Q, W, nq, _qp(oracle, 10, 1, k))
+        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        assert ok, f"{metric} k={k}: {why}"
+        monkeypatch.setenv("WANN_NO_GEMM", "1")
+        ids2, dists2 = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
+        assert pi.counters()["gemm_queries"] == 0
+        assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2)

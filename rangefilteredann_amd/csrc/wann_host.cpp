@@ -423,7 +423,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.graph_count = W.ints.p + I_GRAPH_COUNT;
   ra.heavy_list = W.list_heavy.p;
   ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
-  ra.heavy_ratio = 8;
+  ra.heavy_ratio = getenv("WANN_HEAVY_RATIO") ? atoi(getenv("WANN_HEAVY_RATIO")) : 8;
   ra.brute_list = W.list_brute.p;
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
   ra.spec = spec ? 1 : 0;

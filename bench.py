@@ -334,7 +334,7 @@ def cpu_baseline(np, X, Q, labels, W, nq, beam, mult, cache, params, gpu_ids, gp
     res_path = os.path.join(tmp, "gpu_result.npz")
     np.savez(res_path, ids=gpu_ids, dists=gpu_dists, W=W)
     tried = []
-    for threads in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4)}, reverse=True):
+    for threads in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), max(1, ncpu // 8), max(1, ncpu // 16)}, reverse=True):
         cmd = [sys.executable, os.path.join(REPO, "tools", "ref_baseline.py"), "--threads", str(threads), "--n", str(n), "--nq", str(nq),
                "--dim", str(d), "--beam", str(beam), "--mult", str(mult), "--cache", cache, "--result", res_path]
         try:

@@ -456,7 +456,17 @@ static void build_many(std::vector<Job> &jobs, int threads) {
       J.fresh.assign(J.hi - J.lo, {});
       for (size_t bi = 0; bi < J.hi - J.lo; bi++) items.emplace_back((int32_t)j, (int32_t)bi);
     }
-    if (items.empty()) break;
+    bool any_active = false;
+    for (auto &J : jobs) any_active = any_active || J.active;
+    if (!any_active) break;
+    if (items.empty()) {  // every active partition has an empty batch this round (m = 1, or the step after 2^i - 1 == m - 1)
+      for (auto &J : jobs) {
+        if (!J.active) continue;
+        J.inc++;
+        if (J.count >= (size_t)J.V.n) J.active = false;
+      }
+      continue;
+    }
     round_no++;
     total_items += items.size();
     double t1 = now();

@@ -165,6 +165,7 @@ struct FinalizeArgs {
 // launchers implemented in wann_kernels.hip (all asynchronous on `stream`)
 struct LaunchCfg {
   int blocks;
+  int waves_per_block;  // 0 = kWavesPerBlock
 };
 int launch_route(const RouteArgs &a, void *stream);
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);

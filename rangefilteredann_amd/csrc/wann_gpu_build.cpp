@@ -142,7 +142,17 @@ void gpu_build_graphs(const IndexView &view, int32_t *d_graph, const std::vector
         }
         for (size_t bi = J.lo; bi < J.hi; bi++) items.push_back(BuildItem{targets[j].part_index, J.order[bi]});
       }
-      if (items.empty()) break;
+      bool any_active = false;
+      for (auto &J : jobs) any_active = any_active || J.active;
+      if (!any_active) break;
+      if (items.empty()) {  // every active partition has an empty batch this round
+        for (auto &J : jobs) {
+          if (!J.active) continue;
+          J.inc++;
+          if (J.count >= J.n) J.active = false;
+        }
+        continue;
+      }
       if (items.size() > max_items) throw std::runtime_error("gpu build: internal batch bound exceeded");
       rounds++;
       total_items += items.size();

@@ -257,33 +257,41 @@ void upload_index(wann_index &I) {
 struct RoundCfg {
   LaunchCfg lc;
   int slots;
+  int pool_bytes;    // per-wave LDS pool of this launch
   int table_bits;    // per-slot global seen-filter of 4 << table_bits bytes (0 = none needed)
   int64_t beam_cap;  // per-slot global beam entries (0 = none needed)
 };
 
 // Launch geometry for a k_search launch whose searches run beams in [first_beam, cap].
-RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items) {
+// big_lds: the rare follow-up launch for beams beyond the in-kernel cap -- one wave per workgroup with a
+// pool large enough to keep even a 10 000-entry beam in the LDS (only its seen-filter lives in global memory).
+RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false) {
   RoundCfg rc{};
-  const int pool = kSearchPoolBytes;
-  const int per_block = search_lds_bytes_per_wave(I.view.stride, pool) * kWavesPerBlock;
+  const int wpb = big_lds ? 1 : kWavesPerBlock;
+  const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
+  const int common = search_lds_bytes_per_wave(I.view.stride, 0);
+  int pool = kSearchPoolBytes;
+  if (big_lds) pool = (int)std::min<int64_t>(std::max<int64_t>(cap_bytes, kSearchPoolBytes), 150 * 1024 - common);
+  rc.pool_bytes = pool;
+  const int per_block = (common + pool) * wpb;
   if (per_block > 160 * 1024) throw std::runtime_error("beam-search LDS footprint exceeds 160 KiB");
-  // register budget: the L2 kernel holds a whole 512-B row per lane pair in flight (2 waves/SIMD)
-  int blocks_per_cu = std::min(I.view.metric == 1 ? 4 : 2, (160 * 1024) / per_block);
+  // register budget: the L2 kernel holds two whole 512-B rows per lane pair in flight (2 waves/SIMD)
+  int blocks_per_cu = std::min((I.view.metric == 1 ? 16 : 8) / wpb, (160 * 1024) / per_block);
   blocks_per_cu = std::max(1, blocks_per_cu);
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
-  const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
   const int cap_bits = hash_bits(cap);
   if (cap_bytes + ((int64_t)4 << cap_bits) > pool) {  // some beam of the range keeps its filter in global memory
     rc.table_bits = cap_bits;
     int64_t per_slot = (int64_t)4 << cap_bits;
-    int64_t max_slots = std::max<int64_t>(kWavesPerBlock, ((int64_t)16 << 30) / per_slot);
-    blocks = std::min(blocks, max_slots / kWavesPerBlock);
+    int64_t max_slots = std::max<int64_t>(wpb, ((int64_t)16 << 30) / per_slot);
+    blocks = std::min(blocks, max_slots / wpb);
   }
   if (cap_bytes > pool) rc.beam_cap = (cap + 1) & ~(int64_t)1;
   (void)first_beam;
-  blocks = std::min<int64_t>(blocks, (work_items + kWavesPerBlock - 1) / kWavesPerBlock);
+  blocks = std::min<int64_t>(blocks, (work_items + wpb - 1) / wpb);
   rc.lc.blocks = (int)std::max<int64_t>(blocks, 1);
-  rc.slots = rc.lc.blocks * kWavesPerBlock;
+  rc.lc.waves_per_block = wpb;
+  rc.slots = rc.lc.blocks * wpb;
   return rc;
 }
 
@@ -478,10 +486,11 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.par_done = W.par_done.p;
     sa.sub_hops = W.sub_hops.p;
     sa.sub_cmps = W.sub_cmps.p;
-    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items) {
-      RoundCfg rc = config_for(I, first_beam, cap, items);
+    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds) {
+      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds);
       a.B = (int32_t)first_beam;
       a.cap_inkernel = (int32_t)cap;
+      a.pool_bytes = rc.pool_bytes;
       a.g_table = nullptr;
       a.g_beam = nullptr;
       if (rc.table_bits) {
@@ -513,7 +522,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.next_list = W.list_b.p;
     sa.next_count = W.ints.p + I_NEXT0;
     sa.final_count = W.ints.p + I_FINAL0;
-    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8) + (spec ? nq : 0));
+    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8) + (spec ? nq : 0), false);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
@@ -529,7 +538,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       sb.cursor = W.ints.p + I_CURSOR0 + 1;
       sb.next_list = W.list_a.p;  // cannot be used: cap = max_beam
       sb.next_count = W.ints.p + I_NEXT0 + 1;
-      launch(sb, nb, qp.postfiltering_max_beam, next_n);
+      launch(sb, nb, qp.postfiltering_max_beam, next_n, true);
       HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -560,7 +569,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         sf.is_final = 1;
         sf.next_count = W.ints.p + I_NEXT0 + 2;
         sf.final_count = W.ints.p + I_FINAL0 + 1;
-        launch(sf, fb, fb, cnt);
+        launch(sf, fb, fb, cnt, true);
         HIP_CHECK(hipStreamSynchronize(st));  // grp / cnt are reused by the next group
         gi++;
       }
@@ -889,7 +898,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     sa.cap_inkernel = (int32_t)beam;
     sa.max_beam = INT32_MAX;
     sa.mult = 1;
-    sa.pool_bytes = kSearchPoolBytes;
+    sa.pool_bytes = rc.pool_bytes;
     sa.force_general = getenv("WANN_FORCE_GENERAL") ? 1 : 0;
     sa.k = 1;
     sa.limit = limit;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
   const IndexView &ix = A.ix;
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
-  const int slot = blockIdx.x * kWavesPerBlock + wib;
+  const int slot = blockIdx.x * (blockDim.x >> 6) + wib;  // 4 waves per workgroup, 1 for the large-beam follow-up launch
   const int per_wave = wave_lds_common_bytes(ix.stride) + A.pool_bytes;
   unsigned char *base = smem + (size_t)wib * per_wave;
   u64 *gbeam = A.g_beam ? A.g_beam + (size_t)slot * A.g_beam_cap : nullptr;
@@ -740,8 +740,9 @@ int launch_route(const RouteArgs &a, void *stream) {
 
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream) {
   if (cfg.blocks <= 0) return 0;
-  size_t lds = (size_t)search_lds_bytes_per_wave(a.ix.stride, a.pool_bytes) * kWavesPerBlock;
-  dim3 grid(cfg.blocks), block(64 * kWavesPerBlock);
+  const int wpb = cfg.waves_per_block > 0 ? cfg.waves_per_block : kWavesPerBlock;
+  size_t lds = (size_t)search_lds_bytes_per_wave(a.ix.stride, a.pool_bytes) * wpb;
+  dim3 grid(cfg.blocks), block(64 * wpb);
   hipStream_t s = (hipStream_t)stream;
   if (a.ix.metric == 1) {
     auto kern = k_search<1>;

@@ -324,3 +324,28 @@ def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sf
         ids2, dists2 = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
         assert pi.counters()["gemm_queries"] == 0
         assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2)
+
+
+@pytest.mark.parametrize("n,d", [(1, 4), (2, 3), (7, 5), (300, 5), (300, 17)])
+def test_tiny_shapes(oracle, wa, gpu, n, d):
+    """Degenerate sizes: single-point partitions, dimensions that are not multiples of 4 / 8, windows wider
+    than the data."""
+    rng = np.random.default_rng(n * 31 + d)
+    X = rng.integers(0, 50, size=(n, d)).astype(np.float32)
+    Q = rng.integers(0, 50, size=(9, d)).astype(np.float32)
+    labels = distinct_labels(n, 1)
+    W = np.array([[-1.0, 2.0], [0.0, 0.5], [0.5, 1.0], [0.2, 0.21], [labels[0], labels[0]], [3.0, 4.0], [-2.0, -1.0], [0.0, 1.0], [0.4, 0.6]])
+    for kind, kw in (("VamanaRangeFilterTreeIndex", dict(cutoff=50, split_factor=2)), ("SuperOptimizedPostfilterTreeIndex", dict(cutoff=50, split_factor=2, shift_factor=0.5)),
+                     ("PostfilterVamanaIndex", {}), ("RangeFilterTreeIndex", dict(cutoff=50, split_factor=2))):
+        if n < 7 and kind.endswith("RangeFilterTreeIndex"):
+            continue  # the reference's fenwick lookup indexes past its bucket table on such trees (std::out_of_range)
+        for sfx in ("FloatEuclidian", "FloatMips"):
+            labkw = "filters" if kind == "PostfilterVamanaIndex" else "filter_values"
+            pi = getattr(wa, kind + sfx)(X, **{labkw: labels}, build_params=wa.BuildParams(8, 16, 1.0, ""), **kw)
+            oi = getattr(oracle, kind + sfx)(X, **{labkw: labels}, build_params=oracle.BuildParams(8, 16, 1.0, ""), **kw)
+            for beam, mult in ((1, 1), (4, 3), (16, 1)):
+                a = (Q, W, 9) + (("optimized_postfilter",) if kind.endswith("RangeFilterTreeIndex") else ())
+                ids, dists = pi.batch_search(*a, _qp(wa, beam, mult, 3))
+                eids, edists = oi.batch_search(*a, _qp(oracle, beam, mult, 3))
+                ok, why = gu.same_rows(eids, edists, ids, dists, True)
+                assert ok, f"n={n} d={d} {kind}{sfx} beam={beam} x{mult}: {why}"

@@ -78,3 +78,16 @@ def test_graph_quality_by_oracle_recall(oracle, wa, tmp_path):
         ids, _ = idx.batch_search(Q, W, nq, "optimized_postfilter", oracle.QueryParams(10, 40, final_beam_multiply=2))
         gt = brute_force_gt(X, labels, Q, W, 10, "l2")
         assert recall(gt, ids) > 0.9
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 16, 17, 33, 64])
+def test_tiny_partitions_build_like_the_oracle(oracle, wa, tmp_path, n):
+    """Partitions so small that the batch cap equals their size (empty doubling rounds, single-point batches)."""
+    rng = np.random.default_rng(n)
+    X = rng.integers(0, 100, size=(n, 6)).astype(np.float32)
+    labels = distinct_labels(n, 3)
+    pdir, odir = str(tmp_path / "p") + "/", str(tmp_path / "o") + "/"
+    os.makedirs(pdir), os.makedirs(odir)
+    wa.build_cache_shard(1, 0, X, labels, 1000, 2, 0.5, wa.BuildParams(4, 8, 1.0, pdir), 0, 1, 2)
+    oracle.PostfilterVamanaIndexFloatEuclidian(X, filters=labels, build_params=oracle.BuildParams(4, 8, 1.0, odir), threads=2)
+    assert _read(pdir) == _read(odir)

@@ -10,13 +10,16 @@ constexpr int kSelect = 32;  // candidates kept per query by MFMA score before t
 
 struct GemmGroup {   // queries sharing the window [a, b) of the label argsort
   int64_t a, b;
-  int64_t soff;      // offset of the group's score matrix [qcount][b - a] in `scores`
+  int64_t soff;      // offset of the group's score matrix [qcount][(b - a) rounded up to 4] in `scores`
   int32_t qoff;      // the group's query rows are gq[qoff .. qoff + qcount)
   int32_t qcount;
 };
 
+constexpr int kGemmPointChunk = 2048;  // window positions per workgroup (multiple of 128)
+
 struct GemmTile {
-  int32_t group, q0;  // 32-query tile of a group
+  int32_t group, q0;  // 128-query tile of a group ...
+  int64_t p0;         // ... and the first window position of its kGemmPointChunk-point slice
 };
 
 struct GemmArgs {

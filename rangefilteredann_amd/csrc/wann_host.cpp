@@ -325,16 +325,17 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   for (size_t i = 0; i < order.size();) {
     size_t j = i;
     while (j < order.size() && tasks[order[j]].a == tasks[order[i]].a && tasks[order[j]].b == tasks[order[i]].b) j++;
-    const int64_t w = tasks[order[i]].b - tasks[order[i]].a, qc = (int64_t)(j - i);
-    if (qc >= 16 && w >= 64 && k <= kSelect / 2 && soff + qc * w <= budget) {
+    const int64_t w = tasks[order[i]].b - tasks[order[i]].a, qc = (int64_t)(j - i), wp = (w + 3) & ~(int64_t)3;
+    if (qc >= 16 && w >= 64 && k <= kSelect / 2 && soff + qc * wp <= budget && I.view.stride <= 128) {
       GemmGroup g{tasks[order[i]].a, tasks[order[i]].b, soff, (int32_t)gq.size(), (int32_t)qc};
-      for (int64_t t0 = 0; t0 < qc; t0 += 32) tiles.push_back(GemmTile{(int32_t)groups.size(), (int32_t)t0});
+      for (int64_t t0 = 0; t0 < qc; t0 += 128)
+        for (int64_t p0 = 0; p0 < w; p0 += kGemmPointChunk) tiles.push_back(GemmTile{(int32_t)groups.size(), (int32_t)t0, p0});
       for (size_t t = i; t < j; t++) {
         tq_group.push_back((int32_t)groups.size());
         tq_local.push_back((int32_t)(t - i));
         gq.push_back(order[t]);
       }
-      soff += qc * w;
+      soff += qc * wp;
       groups.push_back(g);
     } else {
       for (size_t t = i; t < j; t++) rest.push_back(order[t]);

@@ -3,7 +3,7 @@ one window per cluster = 1 % of the points, 9 900 queries), PrefilterIndex brute
 dense MFMA path vs the exact per-query scan vs the real reference.  Run from the repo root."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 os.environ.setdefault("PARLAY_NUM_THREADS", str(os.cpu_count()))
 import torch
 import window_ann as wa

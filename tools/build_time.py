@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np, shutil
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))  # run from the repo root
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from util import sift_like
 import window_ann as wa
 n = int(sys.argv[1])

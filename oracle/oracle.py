@@ -55,6 +55,8 @@ def lib():
     if _lib is None:
         build()
         L = C.CDLL(_LIB_PATH)
+        L.orc_random_permutation.restype = None
+        L.orc_random_permutation.argtypes = [C.c_int64, C.c_void_p]
         L.orc_hash64_2.restype = C.c_uint64
         L.orc_hash64_2.argtypes = [C.c_uint64]
         L.orc_hash_bits.restype = C.c_int
@@ -236,6 +238,13 @@ SuperOptimizedPostfilterTreeIndexFloatMips = _mk(SUPER, MIPS, False)
 # ----------------------------------------------------------------------------- raw pieces
 def hash64_2(x: int) -> int:
     return int(lib().orc_hash64_2(C.c_uint64(x & 0xFFFFFFFFFFFFFFFF)))
+
+
+def random_permutation(n: int) -> np.ndarray:
+    """parlay::random_permutation<int>(n) with the default generator (the builder's insertion order)."""
+    out = np.empty(n, dtype=np.int32)
+    lib().orc_random_permutation(n, out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def hash_bits(beam: int) -> int:

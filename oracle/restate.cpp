@@ -403,19 +403,56 @@ std::vector<int32_t> robust_prune(const BuildCtx &C, const Graph &G, int32_t p,
   return out;
 }
 
+// parlay::hash64 (parlay/utilities.h:131-141)
+inline uint64_t hash64(uint64_t u) {
+  uint64_t v = u * 3935559000370003845ul + 2691343689449507681ul;
+  v ^= v >> 21;
+  v ^= v << 37;
+  v ^= v >> 4;
+  v *= 4768777513237032717ul;
+  v ^= v << 20;
+  v ^= v >> 41;
+  v ^= v << 5;
+  return v;
+}
+
+// parlay::random_permutation<int>(n, random()) (parlay/random.h:79-159): below 8192 elements a Knuth
+// shuffle of iota driven by r.ith_rand(i) = hash64(i + state), state 0 (:81-89,97-103); otherwise a STABLE
+// counting sort of iota by hash64(i) & (2^bits - 1) (:105-125; both the sequential and the blocked
+// counting sort keep equal keys in input order, internal/counting_sort.h:48-63,66-74) followed by a
+// Knuth shuffle of every bucket with r.fork(bucket), state = hash64(hash64(bucket)) (:128-133, :53).
+std::vector<int32_t> parlay_random_permutation(int64_t n) {
+  std::vector<int32_t> out((size_t)n);
+  auto knuth = [](int32_t *A, size_t len, uint64_t state) {
+    if (len < 2) return;
+    for (size_t i = len - 1; i > 0; i--) std::swap(A[i], A[hash64(i + state) % (i + 1)]);
+  };
+  if (n < 8192) {
+    for (int64_t i = 0; i < n; i++) out[i] = (int32_t)i;
+    knuth(out.data(), (size_t)n, 0);
+    return out;
+  }
+  size_t lg = 0;  // log2_up (utilities.h:224-233)
+  for (uint64_t b = (uint64_t)n - 1; b > 0; b >>= 1) lg++;
+  const size_t bits = ((uint64_t)n < (1ull << 27)) ? (lg - 7) / 2 : (lg - 17);
+  const size_t nb = (size_t)1 << bits, mask = nb - 1;
+  std::vector<size_t> off(nb + 1, 0);
+  for (int64_t i = 0; i < n; i++) off[(hash64((uint64_t)i) & mask) + 1]++;
+  for (size_t b = 0; b < nb; b++) off[b + 1] += off[b];
+  std::vector<size_t> cur(off.begin(), off.end() - 1);
+  for (int64_t i = 0; i < n; i++) out[cur[hash64((uint64_t)i) & mask]++] = (int32_t)i;
+  for (size_t b = 0; b < nb; b++) knuth(out.data() + off[b], off[b + 1] - off[b], hash64(hash64((uint64_t)b)));
+  return out;
+}
+
 void vamana_build(const BuildCtx &C, Graph &G, int threads) {
   const int64_t n = C.n;
   G.n = n;
   G.maxdeg = C.R;
   G.rows.assign((size_t)n * (C.R + 1), 0);
   if (n == 0) return;
-  // insertion order: the restatement's own permutation (reference: parlay::random_permutation,
-  // vamana/index.h:233) -- argsort of hash64_2(i)
-  std::vector<int32_t> order(n);
-  for (int64_t i = 0; i < n; i++) order[i] = (int32_t)i;
-  std::sort(order.begin(), order.end(), [](int32_t a, int32_t b) {
-    return hash64_2((uint64_t)a) < hash64_2((uint64_t)b);
-  });
+  // insertion order: parlay::random_permutation<int>(n) with the default generator (vamana/index.h:233)
+  std::vector<int32_t> order = parlay_random_permutation(n);
   const int32_t start_point = 0;  // inserts[0] before shuffling (:128)
   size_t max_batch = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);  // :224-226
   if (max_batch == 0) max_batch = (size_t)n;
@@ -920,6 +957,10 @@ void build_super(orc_index &I, int threads) {  // super_optimized_postfilter_tre
 extern "C" {
 
 uint64_t orc_hash64_2(uint64_t x) { return hash64_2(x); }
+void orc_random_permutation(int64_t n, int32_t *out) {
+  std::vector<int32_t> p = parlay_random_permutation(n);
+  memcpy(out, p.data(), (size_t)n * 4);
+}
 int orc_hash_bits(int64_t beam) { return hash_bits(beam); }
 float orc_distance(int metric, const float *p, const float *q, uint32_t d) {
   // defensive copy into zero padded buffers so callers may pass unpadded rows

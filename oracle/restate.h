@@ -42,6 +42,7 @@ typedef struct {
 typedef struct orc_index orc_index;
 
 uint64_t orc_hash64_2(uint64_t x);                 /* parlay/utilities.h:145-150 */
+void orc_random_permutation(int64_t n, int32_t *out); /* parlay/random.h:155-159 (default generator) */
 int orc_hash_bits(int64_t beam);                   /* beamSearch.h:66 */
 float orc_distance(int metric, const float *point, const float *query, uint32_t d);
 
@@ -62,9 +63,11 @@ int orc_graph_save(const char *path, const int32_t *rows, int64_t n, int64_t max
 void orc_free(void *p);
 
 /* Vamana build of ONE partition (vamana/index.h:123-313).  Same batch schedule, beam search,
- * robustPrune, reverse-edge step and final neighbour sort as the reference; insertion order is
- * the restatement's own permutation (argsort of hash64_2(i)) and distance ties break by id, so
- * graphs are deterministic but NOT byte-identical to the reference builder's. */
+ * robustPrune, reverse-edge step, final neighbour sort and insertion order
+ * (parlay::random_permutation, orc_random_permutation) as the reference.  Exact distance ties
+ * break by id (the reference: whatever order libstdc++'s std::sort leaves), so the graph equals
+ * the reference builder's whenever no two candidates are exactly equidistant -- pinned by
+ * tests/golden/build_golden.npz and tests/test_oracle_vs_reference.py. */
 int orc_vamana_build(const float *points, int64_t stride, int64_t d, int metric,
                      int64_t subset_start, int64_t n, int64_t R, int64_t L, double alpha,
                      int32_t *rows /* n*(R+1) */, int threads);

@@ -5,9 +5,10 @@
 // final per-node neighbour sort) with this engine's own data structures: the search frontier is
 // one sorted array of 64-bit keys (order-preserving distance bits | node id | visited bit) merged
 // in place, which is also the representation the gfx950 search kernel uses.  Insertion order is
-// argsort(hash64_2(i)) and distance ties break by id, so builds are deterministic for any thread
-// count (they are not byte-identical to the reference builder's graphs; graphs written by the
-// reference load through the same cache files).
+// the reference's (parlay::random_permutation, insertion_order()) and distance ties break by id, so
+// builds are deterministic for any thread count and the graph files equal the reference builder's
+// whenever no two candidates of a prune / neighbour sort are exactly equidistant (with such ties
+// the reference's order is whatever libstdc++'s std::sort leaves; ours is by id).
 #include "wann_build.h"
 
 #include <algorithm>
@@ -417,6 +418,50 @@ struct Job {
 };
 }  // namespace
 
+// parlay::hash64 (parlay/utilities.h:131-141), the generator behind parlay::random
+static inline uint64_t parlay_hash64(uint64_t u) {
+  uint64_t v = u * UINT64_C(3935559000370003845) + UINT64_C(2691343689449507681);
+  v ^= v >> 21;
+  v ^= v << 37;
+  v ^= v >> 4;
+  v *= UINT64_C(4768777513237032717);
+  v ^= v << 20;
+  v ^= v >> 41;
+  v ^= v << 5;
+  return v;
+}
+
+// The order in which the reference inserts the n points of a graph: parlay::random_permutation<int>(n)
+// with the default generator (vamana/index.h:233; parlay/random.h:79-159).  n < 8192: Fisher-Yates from
+// the back with draws hash64(i); otherwise a stable bucketing of 0..n-1 by the low bits of hash64(i)
+// followed by a Fisher-Yates pass per bucket with draws hash64(i + hash64(hash64(bucket))).  A function
+// of n only, so builds are reproducible for any thread count and match the reference's graphs.
+std::vector<int32_t> insertion_order(int64_t n) {
+  std::vector<int32_t> ord((size_t)std::max<int64_t>(n, 0));
+  auto shuffle = [](int32_t *a, size_t len, uint64_t salt) {
+    for (size_t i = len; i-- > 1;) std::swap(a[i], a[parlay_hash64(i + salt) % (i + 1)]);
+  };
+  if (n < 8192) {
+    for (int64_t i = 0; i < n; i++) ord[(size_t)i] = (int32_t)i;
+    shuffle(ord.data(), ord.size(), 0);
+    return ord;
+  }
+  int lg = 0;
+  while (((uint64_t)1 << lg) < (uint64_t)n) lg++;  // ceil(log2 n)
+  const int bits = ((uint64_t)n < ((uint64_t)1 << 27)) ? (lg - 7) / 2 : lg - 17;
+  const uint64_t nb = (uint64_t)1 << bits;
+  std::vector<size_t> first(nb + 1, 0);
+  std::vector<uint32_t> bucket((size_t)n);
+  for (int64_t i = 0; i < n; i++) first[(bucket[(size_t)i] = (uint32_t)(parlay_hash64((uint64_t)i) & (nb - 1))) + 1]++;
+  for (uint64_t b = 0; b < nb; b++) first[b + 1] += first[b];
+  {
+    std::vector<size_t> fill(first.begin(), first.end() - 1);
+    for (int64_t i = 0; i < n; i++) ord[fill[bucket[(size_t)i]]++] = (int32_t)i;
+  }
+  for (uint64_t b = 0; b < nb; b++) shuffle(ord.data() + first[b], first[b + 1] - first[b], parlay_hash64(parlay_hash64(b)));
+  return ord;
+}
+
 static void build_many(std::vector<Job> &jobs, int threads) {
   const int nthr = std::max(1, threads);
   parallel_for((int64_t)jobs.size(), nthr, [&](int64_t j) {
@@ -425,9 +470,7 @@ static void build_many(std::vector<Job> &jobs, int threads) {
     J.G->n = n;
     J.G->maxdeg = (int32_t)J.V.R;
     J.G->rows.assign((size_t)n * (J.V.R + 1), 0);
-    J.order.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) J.order[i] = (int32_t)i;
-    std::sort(J.order.begin(), J.order.end(), [](int32_t a, int32_t b) { return mix64((uint64_t)a) < mix64((uint64_t)b); });
+    J.order = insertion_order(n);
     J.cap = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);  // vamana/index.h:224-226
     if (J.cap == 0) J.cap = (size_t)n;
     J.active = n > 0;

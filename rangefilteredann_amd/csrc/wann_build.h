@@ -63,6 +63,9 @@ bool graph_file_save(const std::string &path, const HostGraph &g);
 std::string graph_file_name(const BuildSpec &s, float lo, float hi, int64_t n);
 
 // Build the graph of one partition (rows [start, start+n) of pts).
+// parlay::random_permutation<int>(n): the reference's insertion order (vamana/index.h:233, parlay/random.h:79-159)
+std::vector<int32_t> insertion_order(int64_t n);
+
 void vamana_build(const float *pts, int64_t stride, int64_t d, int metric, int64_t start, int64_t n,
                   int64_t R, int64_t L, double alpha, HostGraph &g, int threads);
 

@@ -16,11 +16,6 @@
 namespace wann {
 
 namespace {
-inline uint64_t mix64(uint64_t x) {
-  x = (x ^ (x >> 30)) * UINT64_C(0xbf58476d1ce4e5b9);
-  x = (x ^ (x >> 27)) * UINT64_C(0x94d049bb133111eb);
-  return x ^ (x >> 31);
-}
 struct JobState {
   std::vector<int32_t> order;
   size_t n = 0, cap = 0, count = 0, inc = 0, lo = 0, hi = 0;
@@ -43,9 +38,7 @@ void gpu_build_graphs(const IndexView &view, int32_t *d_graph, const std::vector
     JobState &J = jobs[j];
     const int64_t n = parts[targets[j].part_index].n;
     J.n = (size_t)n;
-    J.order.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) J.order[i] = (int32_t)i;
-    std::sort(J.order.begin(), J.order.end(), [](int32_t a, int32_t b) { return mix64((uint64_t)a) < mix64((uint64_t)b); });
+    J.order = insertion_order(n);
     J.cap = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);  // vamana/index.h:224-226
     if (J.cap == 0) J.cap = (size_t)n;
     J.active = n > 0;

@@ -23,6 +23,14 @@ def load(name):
     return data, graphs
 
 
+BUILD_CASES = ["gauss_l2", "unit_mips"]
+
+
+def load_build():
+    """Builder fixtures: parlay's insertion permutations and two graph files written by the reference."""
+    return np.load(os.path.join(GOLDEN, "build_golden.npz"))
+
+
 def unpack_cache(graphs, kind, dst):
     """Write the reference-built graph cache files of `kind` under dst/ and return the prefix."""
     os.makedirs(dst, exist_ok=True)

@@ -226,6 +226,21 @@ def test_gpu_builder_matches_host_builder(wa, gpu, tmp_path, monkeypatch, kind, 
         assert a == b, f"{f}: GPU-built graph differs from the host-built one"
 
 
+@pytest.mark.parametrize("name", gu.BUILD_CASES)
+def test_gpu_builder_writes_the_references_graph_file(wa, gpu, tmp_path, monkeypatch, name):
+    """The graph the GPU builder writes equals, name and bytes, the file the REAL reference's builder wrote
+    for the same input (continuous coordinates: no exactly equidistant candidates)."""
+    import os
+    data = gu.load_build()
+    X, labels, (R, L, metric) = data[f"{name}|X"], data[f"{name}|labels"], data[f"{name}|meta"]
+    cdir = str(tmp_path) + "/"
+    monkeypatch.delenv("WANN_HOST_BUILD", raising=False)
+    cls = wa.PostfilterVamanaIndexFloatMips if metric else wa.PostfilterVamanaIndexFloatEuclidian
+    cls(X, labels, wa.BuildParams(int(R), int(L), 1.0, cdir))
+    assert os.listdir(cdir) == [data[f"{name}|file_name"].tobytes().decode()]
+    assert open(cdir + os.listdir(cdir)[0], "rb").read() == data[f"{name}|file"].tobytes()
+
+
 # ------------------------------------------------------------------------------------------
 # multi-bucket query methods (fenwick, three_split) and the ratio fallback, against the oracle
 # ------------------------------------------------------------------------------------------

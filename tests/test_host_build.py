@@ -45,6 +45,19 @@ def test_builder_matches_oracle_builder(oracle, wa, tmp_path, name, kind, metric
     assert (rows[:, 0] <= R).all() and (rows[:, 0] >= 0).all()
 
 
+@pytest.mark.parametrize("name", ["gauss_l2", "unit_mips"])
+def test_builder_writes_the_references_graph_file(wa, tmp_path, name):
+    """Continuous inputs (no exactly equidistant candidates): the cache file equals the one the REAL
+    reference's builder wrote (tests/golden/build_golden.npz), name and bytes."""
+    import golden_util as gu
+    data = gu.load_build()
+    X, labels, (R, L, metric) = data[f"{name}|X"], data[f"{name}|labels"], data[f"{name}|meta"]
+    cdir = str(tmp_path) + "/"
+    wa.build_cache_shard(1, int(metric), X, labels, 1000, 2, 0.5, wa.BuildParams(int(R), int(L), 1.0, cdir), 0, 1, 4)
+    assert os.listdir(cdir) == [data[f"{name}|file_name"].tobytes().decode()]
+    assert open(cdir + os.listdir(cdir)[0], "rb").read() == data[f"{name}|file"].tobytes()
+
+
 def test_sharded_build_equals_whole_build(wa, tmp_path):
     n, d = 2500, 32
     X = sift_like(n, d, 3)(n)

@@ -36,3 +36,32 @@ def test_hash_and_bits(oracle):
     assert oracle.hash64_2(1) == 0x5692161D100B05E5
     assert [oracle.hash_bits(b) for b in (1, 10, 40, 64, 65, 80, 160, 320, 640, 1280, 10000)] == \
         [10, 10, 10, 10, 11, 11, 13, 15, 17, 19, 25]
+
+
+# ------------------------------------------------------------------------------------------
+# the graph BUILDER against the reference's (tests/golden/build_golden.npz, make_build_golden.py)
+# ------------------------------------------------------------------------------------------
+def test_insertion_order_is_parlays_random_permutation(oracle):
+    import hashlib
+    data = gu.load_build()
+    seen = 0
+    for key in data.files:
+        tag, _, n = key.partition("|")
+        if tag == "perm":
+            assert np.array_equal(oracle.random_permutation(int(n)), data[key]), f"n={n}"
+            seen += 1
+        elif tag == "perm_sha256":
+            got = hashlib.sha256(oracle.random_permutation(int(n)).tobytes()).digest()
+            assert got == data[key].tobytes(), f"n={n}"
+            seen += 1
+    assert seen >= 10
+
+
+@pytest.mark.parametrize("name", gu.BUILD_CASES)
+def test_oracle_builder_writes_the_references_graph_file(oracle, tmp_path, name):
+    data = gu.load_build()
+    X, (R, L, metric) = data[f"{name}|X"], data[f"{name}|meta"]
+    rows = oracle.vamana_build(oracle.pad_rows(X), X.shape[1], int(metric), 0, X.shape[0], int(R), int(L), 1.0, threads=4)
+    path = str(tmp_path / "g.bin")
+    oracle.graph_save(path, rows)
+    assert open(path, "rb").read() == data[f"{name}|file"].tobytes()

@@ -26,9 +26,14 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 void gpu_build_graphs(const IndexView &view, int32_t *d_graph, const std::vector<PartDesc> &parts,
                       std::vector<GpuBuildTarget> &targets, int64_t R, int64_t L, double alpha, int num_cus,
-                      int threads, void *stream) {
+                      int threads, void *stream, int vis_scale) {
   if (targets.empty()) return;
   hipStream_t st = (hipStream_t)stream;
+  // (re)start from empty rows: a retry after a visited-list overflow must not see the previous attempt
+  for (auto &t : targets) {
+    const PartDesc &pd = parts[t.part_index];
+    HIP_CHECK(hipMemsetAsync(d_graph + pd.row_base * view.rs, 0xFF, (size_t)pd.n * view.rs * sizeof(int32_t), st));
+  }
   const bool verbose = getenv("WANN_VERBOSE") != nullptr;
   const double t_begin = now_s();
   const int rs = view.rs;
@@ -54,7 +59,8 @@ void gpu_build_graphs(const IndexView &view, int32_t *d_graph, const std::vector
 
   const int bits = std::max<int>(10, (int)std::ceil(std::log2((double)(L * L))) - 2);
   const int table_lds = bits <= kMaxLdsBits ? 1 : 0;
-  int vis_cap = (int)(((2 * L + 64 + 63) / 64) * 64) + 64;
+  int vis_cap = (int)(((2 * L * std::max(vis_scale, 1) + 64 + 63) / 64) * 64) + 64;
+  if (const char *e = getenv("WANN_BUILD_VIS_CAP")) vis_cap = std::max(64, atoi(e)) * std::max(vis_scale, 1);  // tests: force the restart path
   const int wpb = build_waves_per_block();
   const int lds_insert = build_lds_bytes_per_wave(view.stride, (int)L, bits, table_lds, vis_cap, (int)R) * wpb;
   if (lds_insert > 160 * 1024) throw std::runtime_error("gpu build: build beam L too large for the LDS budget");

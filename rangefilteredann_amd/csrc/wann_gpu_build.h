@@ -20,6 +20,6 @@ struct GpuBuildTarget {
 // std::runtime_error("gpu build overflow ...") when a visited list exceeds the LDS budget.
 void gpu_build_graphs(const IndexView &view, int32_t *d_graph, const std::vector<PartDesc> &parts,
                       std::vector<GpuBuildTarget> &targets, int64_t R, int64_t L, double alpha, int num_cus,
-                      int threads, void *stream);
+                      int threads, void *stream, int vis_scale = 1);  // visited-list capacity = vis_scale x (2 L + 64)
 
 }  // namespace wann

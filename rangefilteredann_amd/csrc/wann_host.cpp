@@ -621,8 +621,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");
 }
 
-// Graphs missing from the cache: built on the GPU straight into the adjacency pool (default) or, with
-// WANN_HOST_BUILD=1 or after a device-side overflow, by the host builder and then uploaded.
+// Graphs missing from the cache: built on the GPU straight into the adjacency pool (with WANN_HOST_BUILD=1:
+// by the host builder and then uploaded -- a test hook, never a fallback).
 void upload_part_rows(wann_index &I, const HostPart &P, const PartDesc &pd) {
   const int rs = I.view.rs;
   std::vector<int32_t> stage((size_t)P.n * rs);
@@ -640,19 +640,21 @@ void build_pending(wann_index &I, std::vector<HostPart *> &pending) {
       if (std::find(pending.begin(), pending.end(), &P) != pending.end()) targets.push_back(GpuBuildTarget{(int32_t)pi, &P});
       pi++;
     }
-  bool on_host = getenv("WANN_HOST_BUILD") != nullptr;
-  if (!on_host) {
-    try {
-      gpu_build_graphs(I.view, I.d_graph.p, I.parts, targets, s.R, s.L, s.alpha, I.num_cus, s.threads, I.own_stream);
-    } catch (std::runtime_error &e) {
-      if (std::string(e.what()).find("gpu build overflow") == std::string::npos) throw;
-      fprintf(stderr, "[wann] %s; rebuilding on the host\n", e.what());
-      on_host = true;
-    }
-  }
-  if (on_host) {
+  // WANN_HOST_BUILD=1 (tests: the host builder as a cross-check) is the only way onto the host builder; a
+  // visited list that outgrows its LDS buffer restarts the build ON THE GPU with a larger buffer.
+  if (getenv("WANN_HOST_BUILD") != nullptr) {
     build_pending_on_host(H, pending);
     for (auto &t : targets) upload_part_rows(I, *t.part, I.parts[t.part_index]);
+  } else {
+    for (int vis_scale = 1;; vis_scale *= 2) {
+      try {
+        gpu_build_graphs(I.view, I.d_graph.p, I.parts, targets, s.R, s.L, s.alpha, I.num_cus, s.threads, I.own_stream, vis_scale);
+        break;
+      } catch (std::runtime_error &e) {
+        if (std::string(e.what()).find("gpu build overflow: a visited list") == std::string::npos || vis_scale >= 8) throw;
+        if (getenv("WANN_VERBOSE")) fprintf(stderr, "[wann] %s; restarting the GPU build with a %dx buffer\n", e.what(), 2 * vis_scale);
+      }
+    }
   }
   save_built_graphs(H, pending, true);
 }

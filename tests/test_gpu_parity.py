@@ -226,6 +226,22 @@ def test_gpu_builder_matches_host_builder(wa, gpu, tmp_path, monkeypatch, kind, 
         assert a == b, f"{f}: GPU-built graph differs from the host-built one"
 
 
+def test_gpu_builder_restarts_with_a_larger_visited_buffer(wa, gpu, tmp_path, monkeypatch, capfd):
+    """A visited list that outgrows its LDS buffer restarts the build on the GPU (no host fallback): with the
+    buffer forced down to 64 entries the first attempts overflow and the final graph is still the golden one."""
+    import os
+    data = gu.load_build()
+    name = "gauss_l2"
+    X, labels, (R, L, metric) = data[f"{name}|X"], data[f"{name}|labels"], data[f"{name}|meta"]
+    cdir = str(tmp_path) + "/"
+    monkeypatch.delenv("WANN_HOST_BUILD", raising=False)
+    monkeypatch.setenv("WANN_BUILD_VIS_CAP", "64")
+    monkeypatch.setenv("WANN_VERBOSE", "1")
+    wa.PostfilterVamanaIndexFloatEuclidian(X, labels, wa.BuildParams(int(R), int(L), 1.0, cdir))
+    assert "restarting the GPU build" in capfd.readouterr().err
+    assert open(cdir + os.listdir(cdir)[0], "rb").read() == data[f"{name}|file"].tobytes()
+
+
 @pytest.mark.parametrize("name", gu.BUILD_CASES)
 def test_gpu_builder_writes_the_references_graph_file(wa, gpu, tmp_path, monkeypatch, name):
     """The graph the GPU builder writes equals, name and bytes, the file the REAL reference's builder wrote

@@ -393,7 +393,8 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
 void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int64_t nq, int64_t qid_base,
                const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st) {
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
-  if (qp.beam_width <= 0) throw std::runtime_error("beam_width must be positive");
+  // the brute-force classes ignore the beam (the reference driver passes beam_size = 0 there, run_our_method.py:256)
+  if (qp.beam_width <= 0 && I.H.vamana_leaves) throw std::runtime_error("beam_width must be positive");
   if (qp.postfiltering_max_beam > (1 << 20)) throw std::runtime_error("postfiltering_max_beam too large");
   HIP_CHECK(hipSetDevice(I.device));
   Workspace &W = I.ws;

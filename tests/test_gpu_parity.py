@@ -380,3 +380,19 @@ def test_tiny_shapes(oracle, wa, gpu, n, d):
                 eids, edists = oi.batch_search(*a, _qp(oracle, beam, mult, 3))
                 ok, why = gu.same_rows(eids, edists, ids, dists, True)
                 assert ok, f"n={n} d={d} {kind}{sfx} beam={beam} x{mult}: {why}"
+
+
+def test_prefilter_classes_accept_beam_zero(oracle, wa, gpu):
+    """The reference driver calls the brute-force classes with beam_size = 0 (run_our_method.py:256)."""
+    n, d, nq = 1500, 24, 20
+    g = sift_like(n, d, 5)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 2)
+    W = windows(labels, nq, -3, 1)
+    for cls, args in (("PrefilterIndexFloatEuclidian", ()), ("RangeFilterTreeIndexFloatEuclidian", ("fenwick",))):
+        ids, dists = getattr(wa, cls)(X, labels).batch_search(Q, W, nq, *args, _qp(wa, 0, 1, 10))
+        eids, edists = getattr(oracle, cls)(X, labels).batch_search(Q, W, nq, *args, _qp(oracle, 0, 1, 10))
+        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        assert ok, f"{cls}: {why}"
+    with pytest.raises(RuntimeError, match="beam_width must be positive"):
+        wa.PostfilterVamanaIndexFloatEuclidian(X, labels, wa.BuildParams(8, 16, 1.0, "")).batch_search(Q, W, nq, _qp(wa, 0, 1, 10))

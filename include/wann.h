@@ -114,8 +114,10 @@ int wann_batch_search(wann_index *index, const void *queries, const float *range
 /* Device-buffer call: same semantics, every pointer is device memory on the index's device;
  * `query_id_base` is the global row number of queries[0] (the reference uses the query's row
  * number as its "own id", beamSearch.h:128 + range_filter_tree.h:71-72, so a query shard must
- * keep its global numbering).  Runs on `hip_stream` (a hipStream_t, NULL = default stream) and
- * returns after the stream work is complete. */
+ * keep its global numbering).  Runs on `hip_stream` (a hipStream_t; NULL = the HIP default stream,
+ * i.e. ordered after the work the caller queued there) and returns after the stream work is
+ * complete.  With a non-blocking stream the caller must make sure that the inputs are complete and
+ * that no work still pending on another stream uses the output buffers' memory. */
 int wann_batch_search_device(wann_index *index, const void *d_queries, const float *d_ranges,
                              int64_t nq, int64_t query_id_base, const char *method,
                              const wann_query_params *qp, uint32_t *d_ids, float *d_dists,

@@ -731,7 +731,9 @@ int wann_batch_search_device(wann_index *I, const void *d_queries, const float *
   if (!I || !qp || nq < 0) return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_device");
   std::lock_guard<std::mutex> lk(I->mu);
   try {
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : I->own_stream;
+    // NULL = the HIP default stream: ordered after everything the caller queued on its default stream
+    // (torch's current stream unless changed), so freshly produced inputs / recycled output blocks are safe
+    hipStream_t st = (hipStream_t)hip_stream;
     run_batch(*I, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st);
   } catch (HipError &e) {
     return fail(WANN_ERR_HIP, e.what());

@@ -326,12 +326,11 @@ struct Emitter {
   const RouteArgs &A;
   int64_t q;
   int n;
-  bool overflow;
-  __device__ Emitter(const RouteArgs &a, int64_t qq) : A(a), q(qq), n(0), overflow(false) {}
-  __device__ void push(const Task &t) {
+  __device__ Emitter(const RouteArgs &a, int64_t qq) : A(a), q(qq), n(0) {}
+  __device__ __forceinline__ void push(const Task &t) {
     if (t.mode == T_EMPTY) return;
-    if (n >= A.maxt) {
-      overflow = true;
+    if (n >= A.maxt) {  // the host raises an error for the batch
+      atomicAdd(&A.ctr->unsupported, 1ull);
       return;
     }
     const int32_t ti = (int32_t)(q * A.maxt + n);
@@ -346,7 +345,7 @@ struct Emitter {
   }
   // SpatialIndex::query on partition pidx for window [lo,hi]: the post-filter loop on a Vamana
   // leaf (postfilter_vamana.h:141-188), brute force on a PrefilterIndex leaf (prefiltering.h:154-204)
-  __device__ void leaf(int32_t pidx, float lo, float hi, uint64_t w, bool mult_one) {
+  __device__ __forceinline__ void leaf(int32_t pidx, float lo, float hi, uint64_t w, bool mult_one) {
     const IndexView &ix = A.ix;
     Task t;
     t.query = (int32_t)q;
@@ -409,7 +408,7 @@ struct Emitter {
     }
     push(t);
   }
-  __device__ void brute(uint64_t a, uint64_t b) {  // rows [a,b) of the sorted order, no label test
+  __device__ __forceinline__ void brute(uint64_t a, uint64_t b) {  // rows [a,b) of the sorted order, no label test
     if (b <= a) return;
     Task t;
     t.query = (int32_t)q;
@@ -439,7 +438,7 @@ __device__ __forceinline__ int64_t bucket_containing(const int64_t *off, int64_t
 }
 
 // find_largest_ranges_within_query_range (range_filter_tree.h:234-295)
-__device__ bool find_centre(const IndexView &ix, uint64_t istart, uint64_t eend, Centre &c) {
+__device__ __forceinline__ bool find_centre(const IndexView &ix, uint64_t istart, uint64_t eend, Centre &c) {
   const uint64_t range_size = eend - istart;
   int64_t row = -1;
   for (int r = 0; r < ix.nlevels; r++) {
@@ -480,99 +479,120 @@ __device__ bool find_centre(const IndexView &ix, uint64_t istart, uint64_t eend,
   return true;
 }
 
-// fenwick_tree_search (range_filter_tree.h:297-401)
-__device__ void emit_fenwick(Emitter &E, float lo, float hi, bool mult_one) {
-  const IndexView &ix = E.A.ix;
-  if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;  // check_empty
-  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
-  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
-  const uint64_t w = eend - istart;
-  Centre c;
-  if (!find_centre(ix, istart, eend, c)) {
-    E.brute(istart, eend);
-    return;
-  }
-  for (int64_t b = c.first; b < c.last; b++) E.leaf((int32_t)(ix.level_part0[c.row] + b), lo, hi, w, mult_one);
-  uint64_t cov_s = c.cover_start, cov_e = c.cover_end;
-  int64_t left = c.first, right = c.last - 1;
-  const int64_t B = ix.split;
-  for (int64_t row = c.row + 1; row < ix.nlevels; row++) {
-    const int64_t *off = ix.wst_off + ix.wst_ptr[row];
-    const int64_t nb = ix.level_nb[row];
-    left *= B;
-    right = right * B + B - 1;
-    while (left > 0) {
-      const uint64_t nls = (uint64_t)off[left - 1];
-      if (nls < istart) break;
-      cov_s = nls;
-      left -= 1;
-      E.leaf((int32_t)(ix.level_part0[row] + left), lo, hi, w, mult_one);
-    }
-    while (right < nb - 1) {
-      const uint64_t nre = (uint64_t)off[right + 2];
-      if (nre > eend) break;
-      cov_e = nre;
-      right += 1;
-      E.leaf((int32_t)(ix.level_part0[row] + right), lo, hi, w, mult_one);
-    }
-  }
-  E.brute(istart, cov_s);
-  E.brute(cov_e, eend);
-}
+// Tree query methods (range_filter_tree.h:62-96).  The reference's three entry points call each other:
+// three_split_search (:473-540) covers its two remainders with optimized_postfiltering_search (:403-471),
+// which falls back to fenwick_tree_search (:297-401) for tiny windows / a large bucket-to-window ratio.
+// Here one loop walks the (at most three) label windows a query decomposes into and each body exists
+// once, fully inlined: k_route must not need a scratch segment (no calls, no stack objects).
+enum { W_FENWICK = 0, W_OPTIMIZED = 1, W_THREE_SPLIT = 2 };
 
-// optimized_postfiltering_search (range_filter_tree.h:403-471)
-__device__ void emit_optimized(Emitter &E, float lo, float hi) {
+__device__ __forceinline__ void emit_tree(Emitter &E, float lo0, float hi0, int mode0) {
   const IndexView &ix = E.A.ix;
-  if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;
-  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
-  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
-  const uint64_t w = eend - istart;
-  if (4 * w < (uint64_t)(int64_t)ix.cutoff) {  // :419-421
-    emit_fenwick(E, lo, hi, false);
-    return;
-  }
-  int64_t row = 0, idx = 0;
-  while (row + 1 < ix.nlevels) {  // :426-451
-    const int64_t nrow = row + 1;
-    const int64_t *off = ix.wst_off + ix.wst_ptr[nrow];
-    int64_t nidx = -1;
-    for (int64_t c = idx * ix.split; c < idx * ix.split + ix.split; c++) {
-      if (c >= ix.level_nb[nrow]) break;
-      if (istart >= (uint64_t)off[c] && eend <= (uint64_t)off[c + 1]) nidx = c;
-    }
-    if (nidx < 0) break;
-    idx = nidx;
-    row = nrow;
-  }
-  if (E.A.has_ratio) {  // :460-466
-    const int64_t *off = ix.wst_off + ix.wst_ptr[row];
-    const float ratio = (float)(uint64_t)(off[idx + 1] - off[idx]) / (float)w;
-    if (ratio > E.A.ratio) {
-      emit_fenwick(E, lo, hi, false);
-      return;
-    }
-  }
-  E.leaf((int32_t)(ix.level_part0[row] + idx), lo, hi, w, false);
-}
+  float lo1 = 0.f, hi1 = 0.f, lo2 = 0.f, hi2 = 0.f;  // remainders of three_split (always W_OPTIMIZED)
+  int nwin = 1;
+  for (int it = 0; it < nwin; it++) {
+    const float lo = it == 0 ? lo0 : (it == 1 ? lo1 : lo2);
+    const float hi = it == 0 ? hi0 : (it == 1 ? hi1 : hi2);
+    int mode = it == 0 ? mode0 : W_OPTIMIZED;
+    bool mult_one = false;
+    if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) continue;  // check_empty (:191-203)
+    const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
+    const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
+    const uint64_t w = eend - istart;
+    Centre c;
+    bool have_centre = false;
+    if (mode != W_OPTIMIZED) have_centre = find_centre(ix, istart, eend, c);
 
-// three_split_search (range_filter_tree.h:473-540)
-__device__ void emit_three_split(Emitter &E, float lo, float hi) {
-  const IndexView &ix = E.A.ix;
-  if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;
-  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
-  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
-  Centre c;
-  if (!find_centre(ix, istart, eend, c)) {
-    emit_fenwick(E, lo, hi, true);  // qp_fenwick: final_beam_multiply = 1
-    return;
+    if (mode == W_THREE_SPLIT) {  // three_split_search (:473-540)
+      if (have_centre) {
+        for (int64_t b = c.first; b < c.last; b++) E.leaf((int32_t)(ix.level_part0[c.row] + b), lo, hi, w, true);
+        if (c.cover_start - istart > 0) {
+          lo1 = lo;
+          hi1 = ix.labels[c.cover_start];
+          nwin = 2;
+        }
+        if (eend - c.cover_end > 0) {
+          if (nwin == 2) {
+            lo2 = ix.labels[c.cover_end];
+            hi2 = hi;
+          } else {
+            lo1 = ix.labels[c.cover_end];
+            hi1 = hi;
+          }
+          nwin++;
+        }
+        continue;
+      }
+      mode = W_FENWICK;  // qp_fenwick: final_beam_multiply = 1 (:490-498)
+      mult_one = true;
+    }
+
+    if (mode == W_OPTIMIZED) {  // optimized_postfiltering_search (:403-471)
+      bool fallback = 4 * w < (uint64_t)(int64_t)ix.cutoff;  // :419-421
+      if (!fallback) {
+        int64_t row = 0, idx = 0;
+        while (row + 1 < ix.nlevels) {  // :426-451
+          const int64_t nrow = row + 1;
+          const int64_t *off = ix.wst_off + ix.wst_ptr[nrow];
+          int64_t nidx = -1;
+          for (int64_t ch = idx * ix.split; ch < idx * ix.split + ix.split; ch++) {
+            if (ch >= ix.level_nb[nrow]) break;
+            if (istart >= (uint64_t)off[ch] && eend <= (uint64_t)off[ch + 1]) nidx = ch;
+          }
+          if (nidx < 0) break;
+          idx = nidx;
+          row = nrow;
+        }
+        if (E.A.has_ratio) {  // :460-466
+          const int64_t *off = ix.wst_off + ix.wst_ptr[row];
+          const float ratio = (float)(uint64_t)(off[idx + 1] - off[idx]) / (float)w;
+          fallback = ratio > E.A.ratio;
+        }
+        if (!fallback) {
+          E.leaf((int32_t)(ix.level_part0[row] + idx), lo, hi, w, false);
+          continue;
+        }
+      }
+      mode = W_FENWICK;
+      have_centre = find_centre(ix, istart, eend, c);
+    }
+
+    // fenwick_tree_search (:297-401)
+    if (!have_centre) {
+      E.brute(istart, eend);
+      continue;
+    }
+    for (int64_t b = c.first; b < c.last; b++) E.leaf((int32_t)(ix.level_part0[c.row] + b), lo, hi, w, mult_one);
+    uint64_t cov_s = c.cover_start, cov_e = c.cover_end;
+    int64_t left = c.first, right = c.last - 1;
+    const int64_t B = ix.split;
+    for (int64_t row = c.row + 1; row < ix.nlevels; row++) {
+      const int64_t *off = ix.wst_off + ix.wst_ptr[row];
+      const int64_t nb = ix.level_nb[row];
+      left *= B;
+      right = right * B + B - 1;
+      while (left > 0) {
+        const uint64_t nls = (uint64_t)off[left - 1];
+        if (nls < istart) break;
+        cov_s = nls;
+        left -= 1;
+        E.leaf((int32_t)(ix.level_part0[row] + left), lo, hi, w, mult_one);
+      }
+      while (right < nb - 1) {
+        const uint64_t nre = (uint64_t)off[right + 2];
+        if (nre > eend) break;
+        cov_e = nre;
+        right += 1;
+        E.leaf((int32_t)(ix.level_part0[row] + right), lo, hi, w, mult_one);
+      }
+    }
+    E.brute(istart, cov_s);
+    E.brute(cov_e, eend);
   }
-  for (int64_t b = c.first; b < c.last; b++) E.leaf((int32_t)(ix.level_part0[c.row] + b), lo, hi, eend - istart, true);
-  if (c.cover_start - istart > 0) emit_optimized(E, lo, ix.labels[c.cover_start]);
-  if (eend - c.cover_end > 0) emit_optimized(E, ix.labels[c.cover_end], hi);
 }
 
 // super_optimized_postfiltering_search (super_optimized_postfilter_tree.h:187-270)
-__device__ void emit_super(Emitter &E, float lo, float hi) {
+__device__ __forceinline__ void emit_super(Emitter &E, float lo, float hi) {
   const IndexView &ix = E.A.ix;
   if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;
   const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
@@ -607,13 +627,15 @@ __device__ void emit_super(Emitter &E, float lo, float hi) {
   E.leaf((int32_t)(ix.level_part0[level] + idx), lo, hi, w, false);
 }
 
+// KIND is the index class (wann.h WANN_KIND_*; 2 stands for both tree kinds): one small kernel per class.
+template <int KIND>
 __global__ void k_route(RouteArgs A) {
   const IndexView &ix = A.ix;
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= A.nq) return;
   const float lo = A.ranges[2 * q], hi = A.ranges[2 * q + 1];
   Emitter E(A, q);
-  if (ix.kind == 0) {  // PrefilterIndex: [lb(lo), lb(hi)) over the label argsort (prefiltering.h:159-184)
+  if (KIND == 0) {  // PrefilterIndex: [lb(lo), lb(hi)) over the label argsort (prefiltering.h:159-184)
     Task t;
     t.query = (int32_t)q;
     t.part = 0;
@@ -624,7 +646,7 @@ __global__ void k_route(RouteArgs A) {
     t.b = prefilter_bound(ix.fv_sorted, ix.n, hi);
     t.mode = (t.b > t.a) ? T_BRUTE_GATHER : T_EMPTY;
     E.push(t);
-  } else if (ix.kind == 1) {  // stand-alone PostfilterVamanaIndex: always the one graph, no window lookup
+  } else if (KIND == 1) {  // stand-alone PostfilterVamanaIndex: always the one graph, no window lookup
     Task t;
     t.query = (int32_t)q;
     t.part = 0;
@@ -634,17 +656,12 @@ __global__ void k_route(RouteArgs A) {
     t.hi = hi;
     t.mode = (A.beam < A.max_beam) ? T_GRAPH : T_EMPTY;
     E.push(t);
-  } else if (ix.kind == 4) {
+  } else if (KIND == 4) {
     emit_super(E, lo, hi);
-  } else if (A.method == M_OPTIMIZED) {
-    emit_optimized(E, lo, hi);
-  } else if (A.method == M_THREE_SPLIT) {
-    emit_three_split(E, lo, hi);
   } else {
-    emit_fenwick(E, lo, hi, false);
+    emit_tree(E, lo, hi, A.method == M_OPTIMIZED ? W_OPTIMIZED : (A.method == M_THREE_SPLIT ? W_THREE_SPLIT : W_FENWICK));
   }
   A.qtask_cnt[q] = E.n;
-  if (E.overflow) atomicAdd(&A.ctr->unsupported, 1ull);
 }
 
 // One thread per query when every query has at most one task; the multi-task form (fenwick,
@@ -734,7 +751,13 @@ int launch_route(const RouteArgs &a, void *stream) {
   if (a.nq == 0) return 0;
   int threads = 128;
   int blocks = (int)((a.nq + threads - 1) / threads);
-  hipLaunchKernelGGL(k_route, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a.ix.kind) {
+    case 0: hipLaunchKernelGGL(k_route<0>, dim3(blocks), dim3(threads), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(k_route<1>, dim3(blocks), dim3(threads), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(k_route<4>, dim3(blocks), dim3(threads), 0, s, a); break;
+    default: hipLaunchKernelGGL(k_route<2>, dim3(blocks), dim3(threads), 0, s, a); break;
+  }
   return check(hipGetLastError());
 }
 

@@ -55,3 +55,40 @@ def test_uint8_variants_raise(wa):
     X = np.zeros((16, 8), dtype=np.uint8)
     with pytest.raises(RuntimeError, match="float only"):
         wa.VamanaRangeFilterTreeIndexUInt8Euclidian(X, np.arange(16, dtype=np.float32))
+
+
+def test_engine_kernels_use_no_scratch(wa, tmp_path):
+    """None of the engine's own gfx950 kernels may need a private (scratch) segment: a queue whose scratch
+    has to grow between launches was the trigger of GPU memory faults next to other HIP users (torch)
+    in the same process, and scratch traffic is slow anyway.  Reads the code objects inside libwann.so."""
+    import shutil
+    import subprocess
+    import rangefilteredann_amd
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/clang-offload-bundler") and shutil.which("objcopy")):
+        pytest.skip("ROCm llvm tools not present")
+    fat = tmp_path / "fat.bin"
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", rangefilteredann_amd.lib_path(), str(fat)])
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert len(starts) >= 3  # search, build and gemm kernel files
+    seen = {}
+    for i, s in enumerate(starts):
+        part = tmp_path / f"bundle{i}.bin"
+        part.write_bytes(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"co{i}.elf"
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", str(co)], text=True)
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s+\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name and name.startswith("_ZN4wann"):
+                seen[name] = int(m.group(1))
+    assert len(seen) >= 15, seen
+    bad = {k: v for k, v in seen.items() if v != 0}
+    assert not bad, f"kernels with a scratch segment: {bad}"

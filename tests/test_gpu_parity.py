@@ -196,6 +196,42 @@ def test_device_resident_call_matches_host_call(wa, gpu, tmp_path):
     assert np.array_equal(tids.cpu().numpy().view(np.uint32), ids)
 
 
+def test_default_stream_call_is_ordered_with_queued_torch_work(wa, gpu):
+    """Stream 0 = the HIP default stream: the call is ordered after torch work still queued there (exact
+    ground truth by GEMM + topk, whose freed temporaries the caching allocator hands out again as the
+    engine's output rows) and the host-buffer call must return the same rows.  This interleaving used to
+    end in GPU memory faults (k_route needed a scratch segment; NULL meant a private non-blocking stream)."""
+    torch = pytest.importorskip("torch")
+    n, d, nq = 60000, 100, 4000
+    g = unit_mixture(n, d, 2025)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 77)
+    idx = wa.SuperOptimizedPostfilterTreeIndexFloatMips(X, labels, cutoff=1000, split_factor=2, shift_factor=0.5,
+                                                        build_params=wa.BuildParams(32, 100, 1.0, ""))
+    dev = torch.device("cuda:0")
+    Xt, labt, Qt = torch.from_numpy(X).to(dev), torch.from_numpy(labels).to(dev), torch.from_numpy(Q).to(dev)
+    qp = _qp(wa, 10, 2)
+    for it in range(6):
+        W = windows(labels, nq, -6, it).astype(np.float32)
+        Wt = torch.from_numpy(W).to(dev)
+        gt = torch.empty((nq, 10), dtype=torch.int64, device=dev)
+        for a in range(0, nq, 256):  # queued, not waited for
+            s = -(Qt[a:a + 256] @ Xt.T)
+            s.masked_fill_(~((labt[None, :] >= Wt[a:a + 256, 0:1]) & (labt[None, :] <= Wt[a:a + 256, 1:2])), float("inf"))
+            gt[a:a + 256] = torch.topk(s, 10, dim=1, largest=False).indices
+        del s
+        ids_t = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+        dist_t = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+        idx.batch_search_device(Qt.data_ptr(), Wt.data_ptr(), nq, 0, "", qp, ids_t.data_ptr(), dist_t.data_ptr(), 0)
+        got = ids_t.to(torch.int64) & 0xFFFFFFFF
+        rec = float((gt[:, :, None] == got[:, None, :]).any(2).sum(1).double().mean().item() / 10)
+        assert rec > 0.9, (it, rec)
+        ids, dists = idx.batch_search(Q, W, nq, qp)
+        assert np.array_equal(got.cpu().numpy().astype(np.uint32), ids)
+        assert np.array_equal(dist_t.cpu().numpy(), dists)
+        del ids_t, dist_t, gt, Wt
+
+
 # ------------------------------------------------------------------------------------------
 # GPU Vamana build: byte-identical graph files to the host builder (hence to the oracle's builder)
 # ------------------------------------------------------------------------------------------

@@ -306,17 +306,44 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
   const bool mine = lane < c;
   u64 ck = mine ? cand_key[lane] : ~0ull;
   // lower bound of ck in beam[0..m)
-  int lo = 0, hi = m;
-  const int iters = 32 - __builtin_clz(m | 1) + 1;
-  for (int it = 0; it < iters; it++) {
-    if (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      u64 bv = beam[mid] | 1ull;
-      if (bv < (ck | 1ull)) lo = mid + 1;
-      else hi = mid;
+  int pos;
+  if (c <= 16 && m > 64) {
+    // K-ary search: with few candidates (the usual case once the beam is full) K = 64 / c' lanes serve one
+    // candidate and probe K-1 pivots of its interval per step -- about log_K(m) dependent beam reads instead
+    // of log_2(m).  Invariant per group: entries below lo are < key, entries from hi on are >= key.
+    const int logK = (c <= 1) ? 6 : (c <= 2) ? 5 : (c <= 4) ? 4 : (c <= 8) ? 3 : 2;
+    const int K = 1 << logK;
+    const int g = lane >> logK, sub = lane & (K - 1);
+    const u64 gk = (g < c ? cand_key[g] : ~0ull) | 1ull;
+    const u64 gmask = (K == 64) ? ~0ull : (((u64)1 << K) - 1);
+    int lo = 0, hi = m;
+    for (;;) {
+      const bool open = lo < hi;
+      if (ballot64(open) == 0) break;
+      const int width = hi - lo;
+      bool less = false;
+      if (open && sub > 0) less = (beam[lo + ((sub * width) >> logK)] | 1ull) < gk;
+      const int t = popc64((ballot64(less) >> (g << logK)) & gmask);  // pivots 1..t are < key
+      if (open) {
+        const int qt = lo + ((t * width) >> logK), qn = lo + (((t + 1) * width) >> logK);
+        if (t < K - 1) hi = qn;
+        if (t >= 1) lo = qt + 1;
+      }
     }
+    pos = __shfl(lo, (lane << logK) & 63);  // lane i < c: the result of group i
+  } else {
+    int lo = 0, hi = m;
+    const int iters = 32 - __builtin_clz(m | 1) + 1;
+    for (int it = 0; it < iters; it++) {
+      if (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        u64 bv = beam[mid] | 1ull;
+        if (bv < (ck | 1ull)) lo = mid + 1;
+        else hi = mid;
+      }
+    }
+    pos = lo;
   }
-  const int pos = lo;
   // std::set_union keeps max(copies in beam, copies among candidates) of equal elements: the j-th
   // copy of a candidate key is dropped iff the beam already holds more than j copies.  (Copies
   // arise when a row lists a node twice -- the reference's builder can append the start point
@@ -336,18 +363,35 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
   const int p0 = rdlane(pos, ctz64(nd));
   const int span = m - p0;
   if (span > 0) {
-    for (int base = p0 + ((span - 1) & ~63); base >= p0; base -= 64) {
-      int x = base + lane;
-      bool act = x < m;
-      u64 e = act ? beam[x] : 0ull;
-      int sx = 0;
-      for (u64 mm = nd; mm; mm &= mm - 1) {
-        int pl = rdlane(pos, ctz64(mm));
-        sx += (pl <= x) ? 1 : 0;
+    // Shift beam[p0..m) right, highest chunk first, four 64-entry chunks per step (all reads of a step are
+    // issued before its first write: entries only move right, by at most cp <= 64).  An entry moves by the
+    // number of inserted candidates whose position is <= its index: the candidates at or before the
+    // chunk's first index shift the whole chunk (one ballot), the few landing inside it a suffix.
+    const bool ndl = mine && !dup;
+    for (int top = p0 + ((span - 1) & ~63); top >= p0; top -= 256) {
+      u64 ev[4];
+      int nx[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int base = top - 64 * j;
+        nx[j] = B;  // "do not write"
+        ev[j] = 0ull;
+        if (base >= p0) {  // wave-uniform
+          const int x = base + lane;
+          const bool act = x < m;
+          if (act) ev[j] = beam[x];
+          int sx = popc64(ballot64(ndl && pos <= base));
+          for (u64 mm = ballot64(ndl && pos > base && pos <= base + 63); mm; mm &= mm - 1) {
+            const int pl = rdlane(pos, ctz64(mm));
+            sx += (pl <= x) ? 1 : 0;
+          }
+          if (act) nx[j] = x + sx;
+        }
       }
       WAVE_SYNC();
-      int nx = x + sx;
-      if (act && nx < B) beam[nx] = e;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (nx[j] < B) beam[nx[j]] = ev[j];
       WAVE_SYNC();
     }
   }

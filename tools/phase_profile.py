@@ -8,9 +8,11 @@ cache = "/tmp/phase_cache/"; os.makedirs(cache, exist_ok=True)
 lab = np.arange(n, dtype=np.float32)
 idx = wa.PostfilterVamanaIndexFloatEuclidian(X, filters=lab, build_params=wa.BuildParams(64, 500, 1.0, cache))
 rows = idx.partition_graph(0, 0, 64)
-for nq in (64, 8192):
+BEAMS = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (40, 80, 320)
+NQS = tuple(int(x) for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else (64, 8192)
+for nq in NQS:
     Q = g(nq); qids = np.arange(nq, dtype=np.int64) + 10**7
-    for beam in (40, 80, 320):
+    for beam in BEAMS:
         os.environ["WANN_PROFILE_PHASES"] = "1"
         ids, dists, sizes, hops, cmps = wa.raw_beam_search(0, X, rows, 0, Q, qids, beam)
         os.environ.pop("WANN_PROFILE_PHASES")

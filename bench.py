@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--fraction", type=int, default=-3, help="headline window fraction exponent")
-    ap.add_argument("--fractions", default="all", help="'all' = also sweep 2^-16..2^0 (N=1), 'headline' = skip")
+    ap.add_argument("--fractions", default="all", help="'all' = also sweep 2^-16..2^0 (N=1), 'headline' = skip, or a list of exponents '-9,-6'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
@@ -305,9 +305,9 @@ def main():
             result["cpu_baseline"] = None
 
     # ---- all 17 window fractions (configs[1]), device-resident, best setting per fraction
-    if rank == 0 and world == 1 and args.fractions == "all":
+    if rank == 0 and world == 1 and args.fractions != "headline":
         per = {}
-        for p in range(-16, 1):
+        for p in (range(-16, 1) if args.fractions == "all" else [int(x) for x in args.fractions.split(",")]):
             _, _, rws, b = sweep(p, 2000 + p)
             if b is None:
                 b = max(rws, key=lambda r: r["recall"])

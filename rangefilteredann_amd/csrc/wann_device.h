@@ -90,6 +90,11 @@ struct RouteArgs {
   int32_t cap_inkernel;
   int32_t sub_base0, sub_cap;
   int32_t *sub_count;   // next free sub-task slot (relative to sub_base0)
+  // levels whose beam exceeds cap_inkernel but not big_cap go to big_list: they are searched by single
+  // waves that own a whole workgroup's LDS (k_search "big" workgroups), concurrently with everything else
+  int32_t big_cap;      // 0 = no such levels
+  int32_t *big_list, *big_count;  // two classes, longest searches first: beams >= 4096 in big_list[0..), the
+  int32_t big_stride;             // others in big_list[big_stride..); big_count[2]
   Counters *ctr;
 };
 
@@ -113,7 +118,7 @@ struct SearchArgs {
   int32_t pool_bytes;    // per-wave LDS pool for beam + seen-filter
   int32_t is_final;      // this launch is a final re-search: one search, then done
   int32_t *next_list, *next_count;                 // tasks whose next doubling exceeds cap_inkernel
-  int32_t *final_list, *final_beam, *final_count;  // tasks whose final re-search beam exceeds cap_inkernel
+  int32_t *final_list, *final_count;  // tasks whose final re-search beam (recorded in next_beam) exceeds cap_inkernel
   unsigned long long *out_key;  // [ntasks][k]  (fkey(dist) << 32 | sorted id)
   int32_t *out_cnt;             // [ntasks]
   int32_t *g_table;             // per wave slot seen-filter, 4 << g_table_bits bytes each (or null)
@@ -132,6 +137,21 @@ struct SearchArgs {
   int32_t force_general;      // dev / test: never take the small-beam register path
   int32_t *par_done;          // [task slots] finished sub-tasks of a speculating parent
   long long *sub_hops, *sub_cmps;  // [task slots] work of a sub-task (attributed at resolution)
+  // "big" workgroups: in the first nbig_blocks workgroups wave 0 owns the LDS of all four waves and serves
+  // big_list (speculative levels beyond cap_inkernel, beams up to big_cap) before the workgroup joins the
+  // ordinary lists; its seen-filter is g_table_big[blockIdx.x << g_table_big_bits]
+  int32_t nbig_blocks;
+  int32_t big_cap;
+  const int32_t *big_list;   // two classes (see RouteArgs)
+  const int32_t *big_count;
+  int32_t big_stride;
+  int32_t *big_cursor;
+  // tasks leaving through next_list / final_list record the beam they continue with; a follow-up launch
+  // starts each of its tasks at start_beam[task] (null: at B)
+  int32_t *next_beam;
+  const int32_t *start_beam;
+  int32_t *g_table_big;
+  int32_t g_table_big_bits;
 };
 
 struct BruteArgs {

@@ -61,18 +61,19 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
   DevBuf<Task> tasks;
-  DevBuf<int32_t> list_a, list_b, list_final, final_beam, list_heavy, list_brute, ints, out_cnt, g_table, qtask_cnt;
+  DevBuf<int32_t> list_a, list_b, list_final, list_heavy, list_big, list_brute, ints, out_cnt, g_table, g_table_big, qtask_cnt, next_beam;
   DevBuf<unsigned long long> out_key, g_beam;
   DevBuf<long long> sub_hops, sub_cmps;
   DevBuf<int32_t> par_done;
   DevBuf<Counters> ctr;
   DevBuf<float> q_stage, r_stage, dist_stage;
   DevBuf<uint32_t> id_stage;
+  int32_t big_stride = 0;
   int32_t *h_ints = nullptr;  // pinned
   Counters *h_ctr = nullptr;  // pinned
   std::vector<hipEvent_t> ev;
@@ -91,8 +92,10 @@ struct Workspace {
     list_a.ensure(nt);
     list_b.ensure(nt);
     list_final.ensure(nt);
-    final_beam.ensure(nt);
     list_heavy.ensure(nt);
+    list_big.ensure(2 * nt);
+    next_beam.ensure(nt);
+    big_stride = (int32_t)nt;
     list_brute.ensure(nt);
     ints.ensure(kInts);
     out_cnt.ensure(nt);
@@ -442,6 +445,20 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.sub_base0 = (int32_t)(nq * maxt);
   ra.sub_cap = (int32_t)(nq * maxt + sub_slots);
   ra.sub_count = W.ints.p + I_SUB_COUNT;
+  // speculative levels beyond the in-kernel cap: searched by "big" workgroups of the first launch (wave 0 owns
+  // the LDS of all four waves), beams up to big_cap (the LDS beam must fit; 5792^2 < 2^25 bounds the filter
+  // at 32 MiB per workgroup)
+  int32_t big_cap = 0;
+  if (spec && !getenv("WANN_NO_BIG")) {
+    const int common = search_lds_bytes_per_wave(I.view.stride, 0);
+    const int64_t big_pool = (int64_t)(common + kSearchPoolBytes) * kWavesPerBlock - common;
+    big_cap = (int32_t)std::min<int64_t>(big_pool / 8, 5792);
+    if (big_cap <= ra.cap_inkernel || (common + kSearchPoolBytes) * kWavesPerBlock > 160 * 1024) big_cap = 0;
+  }
+  ra.big_cap = big_cap;
+  ra.big_list = W.list_big.p;
+  ra.big_count = W.ints.p + I_BIG_COUNT;
+  ra.big_stride = W.big_stride;
   ra.ctr = W.ctr.p;
   if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
 
@@ -484,17 +501,29 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.out_cnt = W.out_cnt.p;
     sa.ctr = W.ctr.p;
     sa.final_list = W.list_final.p;
-    sa.final_beam = W.final_beam.p;
     sa.par_done = W.par_done.p;
     sa.sub_hops = W.sub_hops.p;
     sa.sub_cmps = W.sub_cmps.p;
-    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds) {
+    sa.next_beam = W.next_beam.p;
+    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0) {
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds);
       a.B = (int32_t)first_beam;
       a.cap_inkernel = (int32_t)cap;
       a.pool_bytes = rc.pool_bytes;
       a.g_table = nullptr;
       a.g_beam = nullptr;
+      a.nbig_blocks = 0;
+      if (with_big_cap > 0) {
+        a.nbig_blocks = std::min(rc.lc.blocks, I.num_cus);  // one per CU: the first num_cus workgroups
+        a.big_cap = with_big_cap;
+        a.big_list = W.list_big.p;
+        a.big_count = W.ints.p + I_BIG_COUNT;
+        a.big_stride = W.big_stride;
+        a.big_cursor = W.ints.p + I_BIG_CURSOR;
+        a.g_table_big_bits = hash_bits(with_big_cap);
+        W.g_table_big.ensure((size_t)a.nbig_blocks << a.g_table_big_bits);
+        a.g_table_big = W.g_table_big.p;
+      }
       if (rc.table_bits) {
         W.g_table.ensure((size_t)rc.slots << rc.table_bits);
         a.g_table = W.g_table.p;
@@ -524,7 +553,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.next_list = W.list_b.p;
     sa.next_count = W.ints.p + I_NEXT0;
     sa.final_count = W.ints.p + I_FINAL0;
-    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8) + (spec ? nq : 0), false);
+    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8) + (spec ? nq : 0), false, big_cap);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
@@ -540,41 +569,52 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       sb.cursor = W.ints.p + I_CURSOR0 + 1;
       sb.next_list = W.list_a.p;  // cannot be used: cap = max_beam
       sb.next_count = W.ints.p + I_NEXT0 + 1;
+      sb.start_beam = W.next_beam.p;  // a task resolved from speculative levels may already be past nb
       launch(sb, nb, qp.postfiltering_max_beam, next_n, true);
       HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
     }
-    // final re-searches whose beam exceeded the in-kernel cap, grouped by beam
+    // final re-searches whose beam exceeded the in-kernel cap: every task at its own beam (next_beam), longest
+    // first, one wave per workgroup with the beam in the LDS; at most two launches (beams <= 4096, which can
+    // run on many more wave slots because their seen-filters are small, then the larger ones)
     const int final_n = W.h_ints[I_FINAL0];
     if (final_n > 0) {
-      std::vector<int32_t> fl((size_t)final_n), fbm((size_t)final_n);
-      HIP_CHECK(hipMemcpy(fl.data(), W.list_final.p, (size_t)final_n * 4, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(fbm.data(), W.final_beam.p, (size_t)final_n * 4, hipMemcpyDeviceToHost));
-      std::vector<int32_t> beams(fbm);
-      std::sort(beams.begin(), beams.end());
-      beams.erase(std::unique(beams.begin(), beams.end()), beams.end());
-      int gi = 0;
-      for (int32_t fb : beams) {
-        std::vector<int32_t> grp;
-        for (int i = 0; i < final_n; i++)
-          if (fbm[i] == fb) grp.push_back(fl[i]);
-        const int32_t cnt = (int32_t)grp.size();
-        if (I_CURSOR0 + 2 + gi >= I_NEXT0) throw std::runtime_error("too many final-beam groups");
-        HIP_CHECK(hipMemcpyAsync(W.list_a.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(W.ints.p + I_GRAPH_COUNT, &cnt, 4, hipMemcpyHostToDevice, st));
+      std::vector<int32_t> fl((size_t)final_n), nbm(W.next_beam.cap);
+      HIP_CHECK(hipMemcpyAsync(fl.data(), W.list_final.p, (size_t)final_n * 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(nbm.data(), W.next_beam.p, nbm.size() * 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      std::sort(fl.begin(), fl.end(), [&](int32_t x, int32_t y) { return nbm[x] != nbm[y] ? nbm[x] > nbm[y] : x < y; });
+      const int nlarge = (int)(std::partition_point(fl.begin(), fl.end(), [&](int32_t x) { return nbm[x] > 4096; }) - fl.begin());
+      HIP_CHECK(hipMemcpyAsync(W.list_final.p, fl.data(), (size_t)final_n * 4, hipMemcpyHostToDevice, st));
+      const int32_t counts[2] = {final_n - nlarge, nlarge};
+      HIP_CHECK(hipMemcpyAsync(W.ints.p + I_FINAL0 + 2, counts, 8, hipMemcpyHostToDevice, st));
+      for (int g = 0; g < 2; g++) {
+        if (counts[g] == 0) continue;
         SearchArgs sf = sa;
-        sf.list = W.list_a.p;
-        sf.list_count = W.ints.p + I_GRAPH_COUNT;
+        sf.list = W.list_final.p + (g == 0 ? nlarge : 0);
+        sf.list_count = W.ints.p + I_FINAL0 + 2 + g;
         sf.heavy_list = nullptr;
         sf.heavy_count = nullptr;
-        sf.cursor = W.ints.p + I_CURSOR0 + 2 + gi;
+        sf.cursor = W.ints.p + I_CURSOR0 + 2 + g;
         sf.is_final = 1;
-        sf.next_count = W.ints.p + I_NEXT0 + 2;
+        sf.start_beam = W.next_beam.p;
+        sf.next_count = W.ints.p + I_NEXT0 + 2;  // unused: a final pass is one search
         sf.final_count = W.ints.p + I_FINAL0 + 1;
-        launch(sf, fb, fb, cnt, true);
-        HIP_CHECK(hipStreamSynchronize(st));  // grp / cnt are reused by the next group
-        gi++;
+        const int64_t gcap = nbm[g == 0 ? fl[nlarge] : fl[0]];  // the group's largest beam
+        launch(sf, gcap, gcap, counts[g], true);
       }
+      HIP_CHECK(hipStreamSynchronize(st));  // fl / counts back the async uploads
+    }
+    if (getenv("WANN_VERBOSE")) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      fprintf(stderr, "[wann batch] beam %ld x%ld: next %d final %d big %d+%d heavy %d;", (long)qp.beam_width, (long)qp.final_beam_multiply,
+              next_n, final_n, W.h_ints[I_BIG_COUNT], W.h_ints[I_BIG_COUNT + 1], W.h_ints[I_HEAVY_COUNT]);
+      for (auto &pr : timed) {
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, W.ev[pr.first], W.ev[pr.second]));
+        fprintf(stderr, " launch %.2f ms", t);
+      }
+      fprintf(stderr, "\n");
     }
   }
 

@@ -47,7 +47,7 @@ __device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:
 }
 
 template <int METRIC>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A) {  // 2 waves per SIMD: at most 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id();
@@ -59,11 +59,42 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
   int32_t *gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
   const int heavy = A.heavy_count ? *A.heavy_count : 0;
   const int total = heavy + *A.list_count;
+  // per-mode parameters (wave-uniform): ordinary = one of four independent waves with its own LDS slice;
+  // big = wave 0 of one of the first nbig_blocks workgroups with the whole workgroup's LDS
+  int pool_bytes = A.pool_bytes, cap = A.cap_inkernel;
+  bool big = (int)blockIdx.x < A.nbig_blocks;
+  int big_total = 0, big_first = 0;
+  if (big) {
+    big_first = A.big_count[0];
+    big_total = big_first + A.big_count[1];
+    if (wib != 0) {  // waves 1-3 sleep at the barrier until wave 0 has drained the big list
+      __syncthreads();
+      big = false;
+    } else {
+      pool_bytes = per_wave * (int)(blockDim.x >> 6) - wave_lds_common_bytes(ix.stride);
+      cap = A.big_cap;
+      gtable = A.g_table_big + ((size_t)blockIdx.x << A.g_table_big_bits);
+    }
+  }
 
   for (;;) {
-    const int t = wave_ticket(A.cursor);
-    if (t >= total) break;
-    int ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
+    int ti;
+    if (big) {
+      const int t = wave_ticket(A.big_cursor);
+      if (t >= big_total) {  // back to an ordinary wave
+        __syncthreads();
+        big = false;
+        pool_bytes = A.pool_bytes;
+        cap = A.cap_inkernel;
+        gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
+        continue;
+      }
+      ti = (t < big_first) ? A.big_list[t] : A.big_list[A.big_stride + t - big_first];
+    } else {
+      const int t = wave_ticket(A.cursor);
+      if (t >= total) break;
+      ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
+    }
     Task task = A.tasks[ti];
     const PartDesc part = ix.parts[task.part];
     const int64_t qrow = task.query;
@@ -74,12 +105,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
     bool final_pass = A.is_final != 0;
     bool sub = (task.flags & 4) != 0;  // speculative sub-task: ONE search at beam B << level
     if (sub) b = (long long)A.B << (int)task.a;
+    else if (A.start_beam) b = A.start_beam[ti];
     for (;;) {  // postfilter_vamana.h:161-181
       const int B = (int)b;
       const int bits = hash_bits_dev(b);
       const int beam_bytes = ((B + 1) & ~1) * 8;
-      const bool beam_lds = beam_bytes <= A.pool_bytes;
-      const bool table_lds = beam_lds && (beam_bytes + (4 << bits) <= A.pool_bytes);
+      const bool beam_lds = beam_bytes <= pool_bytes;
+      const bool table_lds = beam_lds && (beam_bytes + (4 << bits) <= pool_bytes);
       WaveLds L = carve_wave_lds(base, ix.stride, B, beam_lds);
       // stage the query (zero padded); every search restarts from scratch
       for (int i = lane; i < ix.stride; i += 64) L.qv[i] = (i < ix.d) ? A.queries[qrow * ix.d + i] : 0.f;
@@ -97,7 +129,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
         // the part of the pool that the beam leaves free serves as the clash-detection scratch
         int32_t *mini = nullptr;
         uint32_t mini_mask = 0;
-        const int free_words = (A.pool_bytes - beam_bytes) >> 2;
+        const int free_words = (pool_bytes - beam_bytes) >> 2;
         if (free_words >= 1024 && !A.force_general) {
           mini = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(L.lbeam) + beam_bytes);
           mini_mask = (1u << (31 - __builtin_clz((unsigned)free_words))) - 1u;
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
         long long fb = b * ((task.flags & 2) ? 1 : A.mult);
         if (fb > A.max_beam) fb = A.max_beam;
         if (fb <= b) break;
-        if (fb <= A.cap_inkernel) {
+        if (fb <= cap) {
           b = fb;
           final_pass = true;
           continue;
@@ -220,14 +252,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
         if (lane == 0) {
           int at = atomicAdd(A.final_count, 1);
           A.final_list[at] = ti;
-          A.final_beam[at] = (int32_t)fb;
+          A.next_beam[ti] = (int32_t)fb;
         }
         break;
       }
       const long long nb = 2 * b;
       if (nb >= A.max_beam) break;  // cannot double any more: the short result stands
-      if (nb > A.cap_inkernel) {
-        if (lane == 0) A.next_list[atomicAdd(A.next_count, 1)] = ti;
+      if (nb > cap) {
+        if (lane == 0) {
+          A.next_list[atomicAdd(A.next_count, 1)] = ti;
+          if (A.next_beam) A.next_beam[ti] = (int32_t)nb;
+        }
         break;
       }
       b = nb;
@@ -370,7 +405,7 @@ struct Emitter {
           int nsub = 0;
           long long bb = A.beam;
           const unsigned long long need = (unsigned long long)A.k * (uint64_t)pd.n;
-          while (bb < A.max_beam && bb <= A.cap_inkernel && nsub < 12) {
+          while (bb < A.max_beam && (bb <= A.cap_inkernel || bb <= A.big_cap) && nsub < 12) {
             nsub++;
             if ((unsigned long long)bb * w >= need * (unsigned long long)A.spec_num / 8ull) break;
             bb *= 2;
@@ -392,7 +427,11 @@ struct Emitter {
                 st.b = pti;
                 const int32_t sti = A.sub_base0 + base + r;
                 A.tasks[sti] = st;
-                A.heavy_list[atomicAdd(A.heavy_count, 1)] = sti;
+                if (((long long)A.beam << r) > A.cap_inkernel) {
+                  const int cls = (((long long)A.beam << r) >= 4096) ? 0 : 1;
+                  A.big_list[cls * A.big_stride + atomicAdd(A.big_count + cls, 1)] = sti;
+                }
+                else A.heavy_list[atomicAdd(A.heavy_count, 1)] = sti;
               }
               return;
             }

@@ -350,6 +350,37 @@ def test_scheduling_variants_return_identical_rows(wa, gpu, tmp_path, monkeypatc
                     assert b[2:] == cur[2:], (env, key, b[2:], cur[2:])
 
 
+def test_big_workgroup_levels_return_identical_rows(wa, gpu, monkeypatch):
+    """Windows that are a tiny share of their partition double far beyond the in-kernel cap (1280): those levels
+    are searched speculatively by single waves that own a whole workgroup's LDS.  With that path off
+    (WANN_NO_BIG: sequential follow-up launches) or all speculation off the rows and the counters must not change."""
+    n, d, nq = 150000, 64, 1500
+    g = sift_like(n, d, 14)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 16)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, ""))
+    W = windows(labels, nq, -9, seed=5)
+    base = {}
+    for env in ({}, {"WANN_NO_BIG": "1"}, {"WANN_NO_SPEC": "1"}):
+        for k_ in ("WANN_NO_SPEC", "WANN_NO_BIG"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        for beam, mult in [(10, 1), (80, 2)]:
+            ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+            c = idx.counters()
+            cur = (ids.copy(), dists.copy(), c["beam_searches"], c["hops"], c["dist_cmps"])
+            if not env:
+                assert c["beam_searches"] > 1.5 * nq  # the doubling loop is really exercised
+                base[(beam, mult)] = cur
+            else:
+                b = base[(beam, mult)]
+                assert np.array_equal(b[0], cur[0]) and np.array_equal(b[1], cur[1]), (env, beam, mult)
+                assert b[2:] == cur[2:], (env, beam, mult, b[2:], cur[2:])
+                if "WANN_NO_BIG" in env and beam == 10:
+                    assert c["rounds"] >= 2  # some task doubled beyond the cap: the follow-up launch ran
+
+
 # ------------------------------------------------------------------------------------------
 # dense prefilter path (queries sharing a window -> MFMA GEMM + exact re-rank), adversarial-style data
 # (generate_datasets/generate_advserial_dataset.py:8-69: clusters, labels c - 0.5 + U(0,1), one window per cluster)

@@ -134,6 +134,7 @@ struct SearchArgs {
   long long *raw_hops, *raw_cmps;
   const long long *raw_qids;  // raw mode: Point::id() of each query
   unsigned long long *prof;   // dev tool: 5 per-phase cycle counters (or null)
+  long long *trace;           // dev tool: trace[0] = records, then {task, beam, start, end} per search in 100 MHz ticks (or null)
   int32_t force_general;      // dev / test: never take the small-beam register path
   int32_t *par_done;          // [task slots] finished sub-tasks of a speculating parent
   long long *sub_hops, *sub_cmps;  // [task slots] work of a sub-task (attributed at resolution)
@@ -152,6 +153,13 @@ struct SearchArgs {
   const int32_t *start_beam;
   int32_t *g_table_big;
   int32_t g_table_big_bits;
+  // Continuations: an ordinary wave whose task must double beyond cap_inkernel (its speculative levels all
+  // failed) hands it to a "poller" -- wave 0 of the first npollers big workgroups, which after the static big
+  // list waits for such items until every ordinary ticket is done -- instead of to a follow-up launch.
+  int32_t npollers;
+  int32_t *dyn_list;    // [tasks], preset to -1
+  int32_t *dyn_count, *dyn_cursor;
+  int32_t *done_count;  // ordinary tickets completed
 };
 
 struct BruteArgs {

@@ -61,7 +61,7 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
@@ -93,7 +93,7 @@ struct Workspace {
     list_b.ensure(nt);
     list_final.ensure(nt);
     list_heavy.ensure(nt);
-    list_big.ensure(2 * nt);
+    list_big.ensure(3 * nt);
     next_beam.ensure(nt);
     big_stride = (int32_t)nt;
     list_brute.ensure(nt);
@@ -505,6 +505,14 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.sub_hops = W.sub_hops.p;
     sa.sub_cmps = W.sub_cmps.p;
     sa.next_beam = W.next_beam.p;
+    DevBuf<long long> d_trace;  // dev tool: WANN_TASK_TRACE=<file> dumps one line per beam search
+    const char *trace_path = getenv("WANN_TASK_TRACE");
+    const size_t trace_cap = (size_t)1 << 20;
+    if (trace_path) {
+      d_trace.ensure(1 + 4 * trace_cap);
+      HIP_CHECK(hipMemsetAsync(d_trace.p, 0, 8, st));
+      sa.trace = d_trace.p;
+    }
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0) {
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds);
       a.B = (int32_t)first_beam;
@@ -513,6 +521,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       a.g_table = nullptr;
       a.g_beam = nullptr;
       a.nbig_blocks = 0;
+      a.npollers = 0;
+      a.done_count = nullptr;
       if (with_big_cap > 0) {
         a.nbig_blocks = std::min(rc.lc.blocks, I.num_cus);  // one per CU: the first num_cus workgroups
         a.big_cap = with_big_cap;
@@ -523,6 +533,14 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         a.g_table_big_bits = hash_bits(with_big_cap);
         W.g_table_big.ensure((size_t)a.nbig_blocks << a.g_table_big_bits);
         a.g_table_big = W.g_table_big.p;
+        if (!getenv("WANN_NO_POLLERS")) {
+          a.npollers = std::min(a.nbig_blocks / 8, 16);  // never more than a fraction of the launch: pollers do no ordinary work
+          a.dyn_list = W.list_big.p + 2 * (size_t)W.big_stride;
+          a.dyn_count = W.ints.p + I_DYN_COUNT;
+          a.dyn_cursor = W.ints.p + I_DYN_CURSOR;
+          a.done_count = W.ints.p + I_DONE;
+          HIP_CHECK(hipMemsetAsync(a.dyn_list, 0xFF, (size_t)W.big_stride * sizeof(int32_t), st));
+        }
       }
       if (rc.table_bits) {
         W.g_table.ensure((size_t)rc.slots << rc.table_bits);
@@ -604,6 +622,17 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         launch(sf, gcap, gcap, counts[g], true);
       }
       HIP_CHECK(hipStreamSynchronize(st));  // fl / counts back the async uploads
+    }
+    if (trace_path) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<long long> h(1 + 4 * trace_cap);
+      HIP_CHECK(hipMemcpy(h.data(), d_trace.p, h.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(trace_path, "w")) {
+        for (long long i = 0; i < std::min<long long>(h[0], (long long)trace_cap); i++)
+          fprintf(f, "%lld %lld %lld %lld %lld %lld\n", h[1 + 4 * i] & 0xffffffffll, (h[1 + 4 * i] >> 40) & 1, (h[1 + 4 * i] >> 41) & 1, h[2 + 4 * i],
+                  h[3 + 4 * i], h[4 + 4 * i]);
+        fclose(f);
+      }
     }
     if (getenv("WANN_VERBOSE")) {
       HIP_CHECK(hipStreamSynchronize(st));

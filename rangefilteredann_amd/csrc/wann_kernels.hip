@@ -77,12 +77,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
     }
   }
 
+  bool poll = false;  // big mode, static list drained: serving continuations
   for (;;) {
     int ti;
-    if (big) {
+    bool dyn = false;
+    if (big && !poll) {
       const int t = wave_ticket(A.big_cursor);
-      if (t >= big_total) {  // back to an ordinary wave
-        __syncthreads();
+      if (t >= big_total) {
+        if ((int)blockIdx.x < A.npollers && big_total > 0) {  // (pollers only in batches that have big levels at all)
+          poll = true;
+          continue;
+        }
+        __syncthreads();  // back to four ordinary waves
         big = false;
         pool_bytes = A.pool_bytes;
         cap = A.cap_inkernel;
@@ -90,11 +96,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
         continue;
       }
       ti = (t < big_first) ? A.big_list[t] : A.big_list[A.big_stride + t - big_first];
+    } else if (big) {
+      // wait for continuation number d, or for the end of all ordinary work (a producer publishes its item
+      // before it reports its ticket done, so the item count is final once done_count == total)
+      const int d = wave_ticket(A.dyn_cursor);
+      int item = -1;
+      for (int spin = 0; spin < (1 << 22); spin++) {
+        int have = 0, fin = 0;
+        if (lane == 0) {
+          // relaxed device-scope atomics: served by the memory side, no cache invalidation per poll
+          fin = __hip_atomic_load(A.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total;
+          have = __hip_atomic_load(A.dyn_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > d;
+          if (have) item = __hip_atomic_load(A.dyn_list + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        item = uni(item);
+        if (item >= 0 || (uni(fin) && !uni(have))) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+      if (item < 0) {  // nothing more can arrive
+        __syncthreads();
+        big = false;
+        poll = false;
+        pool_bytes = A.pool_bytes;
+        cap = A.cap_inkernel;
+        gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
+        continue;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer's writes (next_beam) before its publication
+      ti = item;
+      dyn = true;
     } else {
       const int t = wave_ticket(A.cursor);
       if (t >= total) break;
       ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
     }
+    const bool ordinary_ticket = !big;
     Task task = A.tasks[ti];
     const PartDesc part = ix.parts[task.part];
     const int64_t qrow = task.query;
@@ -104,7 +140,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
     long long b = A.B;
     bool final_pass = A.is_final != 0;
     bool sub = (task.flags & 4) != 0;  // speculative sub-task: ONE search at beam B << level
-    if (sub) b = (long long)A.B << (int)task.a;
+    if (dyn) {  // a continuation: a plain task or a resolved parent, at the beam its producer recorded
+      sub = false;
+      b = __hip_atomic_load(A.next_beam + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (sub) b = (long long)A.B << (int)task.a;
     else if (A.start_beam) b = A.start_beam[ti];
     for (;;) {  // postfilter_vamana.h:161-181
       const int B = (int)b;
@@ -118,6 +157,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       WAVE_SYNC();
       int m;
       long long nvis, ncmp;
+      const long long trace_t0 = A.trace ? (long long)wall_clock64() : 0;
       if (table_lds && B <= 64 && !A.force_general)
         wave_beam_search_small<METRIC, 1>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
       else if (table_lds && B <= 128 && !A.force_general)
@@ -141,6 +181,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
         wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
                                                       nullptr, 0, m, nvis, ncmp, A.prof);
       auto beam_ld = [&](int i) -> u64 { return beam_lds ? L.lbeam[i] : gbeam[i]; };
+      if (A.trace && lane == 0) {
+        long long *rec = A.trace + 1 + 4 * atomicAdd((unsigned long long *)A.trace, 1ull);
+        rec[0] = ti | (sub ? 1ll << 40 : 0) | (big ? 1ll << 41 : 0);
+        rec[1] = B;
+        rec[2] = trace_t0;
+        rec[3] = (long long)wall_clock64();
+      }
       if (lane == 0) {
         if (sub) {  // attributed when the parent is resolved
           A.sub_hops[ti] = nvis;
@@ -260,12 +307,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       if (nb >= A.max_beam) break;  // cannot double any more: the short result stands
       if (nb > cap) {
         if (lane == 0) {
-          A.next_list[atomicAdd(A.next_count, 1)] = ti;
           if (A.next_beam) A.next_beam[ti] = (int32_t)nb;
+          if (A.npollers > 0 && nb <= A.big_cap && A.big_count[0] + A.big_count[1] > 0) {  // to a poller of this launch
+            __threadfence();
+            const int d = atomicAdd(A.dyn_count, 1);
+            __hip_atomic_store(A.dyn_list + d, ti, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            A.next_list[atomicAdd(A.next_count, 1)] = ti;
+          }
         }
         break;
       }
       b = nb;
+    }
+    if (ordinary_ticket && A.done_count) {
+      WAVE_SYNC();
+      // relaxed: a continuation is published by an atomic whose result this wave has already waited for, so it
+      // is counted in dyn_count before this ticket is counted as done; no cache write-back per ticket
+      if (lane == 0) __hip_atomic_fetch_add(A.done_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

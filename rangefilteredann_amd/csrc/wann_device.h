@@ -138,11 +138,9 @@ struct SearchArgs {
   int32_t force_general;      // dev / test: never take the small-beam register path
   int32_t *par_done;          // [task slots] finished sub-tasks of a speculating parent
   long long *sub_hops, *sub_cmps;  // [task slots] work of a sub-task (attributed at resolution)
-  // "big" workgroups: in the first nbig_blocks workgroups wave 0 owns the LDS of all four waves and serves
-  // big_list (speculative levels beyond cap_inkernel, beams up to big_cap) before the workgroup joins the
-  // ordinary lists; its seen-filter is g_table_big[blockIdx.x << g_table_big_bits]
-  int32_t nbig_blocks;
-  int32_t big_cap;
+  // companion "big" launch (k_search<METRIC, true>): one wave per workgroup with a large LDS pool serves
+  // big_list (speculative levels beyond the ordinary kernel's cap_inkernel, beams up to big_cap)
+  int32_t big_cap;           // ordinary kernel: continuations up to this beam may go to a poller (0: none)
   const int32_t *big_list;   // two classes (see RouteArgs)
   const int32_t *big_count;
   int32_t big_stride;
@@ -151,12 +149,11 @@ struct SearchArgs {
   // starts each of its tasks at start_beam[task] (null: at B)
   int32_t *next_beam;
   const int32_t *start_beam;
-  int32_t *g_table_big;
-  int32_t g_table_big_bits;
   // Continuations: an ordinary wave whose task must double beyond cap_inkernel (its speculative levels all
-  // failed) hands it to a "poller" -- wave 0 of the first npollers big workgroups, which after the static big
-  // list waits for such items until every ordinary ticket is done -- instead of to a follow-up launch.
+  // failed) hands it to a "poller" -- one of the first npollers workgroups of the big launch, which after the
+  // static big list waits for such items until every ordinary ticket is done -- instead of to a follow-up launch.
   int32_t npollers;
+  int32_t yield_for_big;  // ordinary launch: workgroups [0, #big items) exit at once (room for the companion launch)
   int32_t *dyn_list;    // [tasks], preset to -1
   int32_t *dyn_count, *dyn_cursor;
   int32_t *done_count;  // ordinary tickets completed
@@ -194,6 +191,7 @@ struct FinalizeArgs {
 struct LaunchCfg {
   int blocks;
   int waves_per_block;  // 0 = kWavesPerBlock
+  int big;              // the companion kernel for levels beyond cap_inkernel (k_search<METRIC, true>)
 };
 int launch_route(const RouteArgs &a, void *stream);
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);

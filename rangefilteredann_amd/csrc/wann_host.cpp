@@ -77,10 +77,12 @@ struct Workspace {
   int32_t *h_ints = nullptr;  // pinned
   Counters *h_ctr = nullptr;  // pinned
   std::vector<hipEvent_t> ev;
+  hipEvent_t ev_side = nullptr;  // end of the companion (big) launch on the index's side stream
   ~Workspace() {
     if (h_ints) (void)hipHostFree(h_ints);
     if (h_ctr) (void)hipHostFree(h_ctr);
     for (auto e : ev) (void)hipEventDestroy(e);
+    if (ev_side) (void)hipEventDestroy(ev_side);
   }
   void ensure(int64_t nq, int k, int maxt, int64_t sub_slots) {
     const size_t nt = (size_t)nq * maxt + (size_t)sub_slots;
@@ -103,6 +105,7 @@ struct Workspace {
     ctr.ensure(1);
     if (!h_ints) HIP_CHECK(hipHostMalloc((void **)&h_ints, kInts * sizeof(int32_t)));
     if (!h_ctr) HIP_CHECK(hipHostMalloc((void **)&h_ctr, sizeof(Counters)));
+    if (!ev_side) HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
     while (ev.size() < 2 + 4 * kMaxRounds) {
       hipEvent_t e;
       HIP_CHECK(hipEventCreate(&e));
@@ -136,10 +139,12 @@ struct wann_index {
   DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_sel_pos, g_sel_cnt;
   DevBuf<float> g_scores, g_sel_cut;
   hipStream_t own_stream = nullptr;
+  hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
   wann_counters last{};
   std::mutex mu;
   ~wann_index() {
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
   }
 };
 
@@ -156,6 +161,11 @@ void upload_index(wann_index &I) {
   if (arch.rfind("gfx950", 0) != 0)
     throw HipError("device " + std::to_string(I.device) + " is " + arch + ", this library holds gfx950 code only");
   HIP_CHECK(hipStreamCreateWithFlags(&I.own_stream, hipStreamNonBlocking));
+  {  // highest priority: when both launches become ready the companion's few workgroups are dispatched first
+    int prio_low = 0, prio_high = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    HIP_CHECK(hipStreamCreateWithPriority(&I.side_stream, hipStreamNonBlocking, prio_high));
+  }
 
   IndexView &v = I.view;
   v.n = s.n;
@@ -520,25 +530,42 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       a.pool_bytes = rc.pool_bytes;
       a.g_table = nullptr;
       a.g_beam = nullptr;
-      a.nbig_blocks = 0;
       a.npollers = 0;
       a.done_count = nullptr;
+      a.big_cap = 0;
+      a.yield_for_big = 0;
+      bool with_big = false;
+      SearchArgs big{};
+      LaunchCfg big_lc{};
       if (with_big_cap > 0) {
-        a.nbig_blocks = std::min(rc.lc.blocks, I.num_cus);  // one per CU: the first num_cus workgroups
-        a.big_cap = with_big_cap;
-        a.big_list = W.list_big.p;
+        // companion launch for the speculative levels beyond `cap`: one wave per workgroup, one workgroup per
+        // CU, the beam (up to with_big_cap entries) in the LDS, the seen-filter in g_table_big
+        with_big = true;
+        const int common = search_lds_bytes_per_wave(I.view.stride, 0);
+        big = a;
+        big.cap_inkernel = with_big_cap;
+        big.pool_bytes = (common + kSearchPoolBytes) * kWavesPerBlock - common;
+        big.big_list = W.list_big.p;
+        big.big_count = W.ints.p + I_BIG_COUNT;
+        big.big_stride = W.big_stride;
+        big.big_cursor = W.ints.p + I_BIG_CURSOR;
+        big.g_beam = nullptr;
+        big.g_table_bits = hash_bits(with_big_cap);
+        big_lc.blocks = I.num_cus;
+        big_lc.waves_per_block = 1;
+        big_lc.big = 1;
+        W.g_table_big.ensure((size_t)big_lc.blocks << big.g_table_bits);
+        big.g_table = W.g_table_big.p;
+        a.yield_for_big = getenv("WANN_NO_YIELD") ? 0 : 1;
         a.big_count = W.ints.p + I_BIG_COUNT;
-        a.big_stride = W.big_stride;
-        a.big_cursor = W.ints.p + I_BIG_CURSOR;
-        a.g_table_big_bits = hash_bits(with_big_cap);
-        W.g_table_big.ensure((size_t)a.nbig_blocks << a.g_table_big_bits);
-        a.g_table_big = W.g_table_big.p;
         if (!getenv("WANN_NO_POLLERS")) {
-          a.npollers = std::min(a.nbig_blocks / 8, 16);  // never more than a fraction of the launch: pollers do no ordinary work
-          a.dyn_list = W.list_big.p + 2 * (size_t)W.big_stride;
-          a.dyn_count = W.ints.p + I_DYN_COUNT;
-          a.dyn_cursor = W.ints.p + I_DYN_CURSOR;
-          a.done_count = W.ints.p + I_DONE;
+          a.npollers = big.npollers = 16;
+          a.big_cap = with_big_cap;
+          a.big_count = W.ints.p + I_BIG_COUNT;
+          a.dyn_list = big.dyn_list = W.list_big.p + 2 * (size_t)W.big_stride;
+          a.dyn_count = big.dyn_count = W.ints.p + I_DYN_COUNT;
+          a.dyn_cursor = big.dyn_cursor = W.ints.p + I_DYN_CURSOR;
+          a.done_count = big.done_count = W.ints.p + I_DONE;
           HIP_CHECK(hipMemsetAsync(a.dyn_list, 0xFF, (size_t)W.big_stride * sizeof(int32_t), st));
         }
       }
@@ -554,7 +581,13 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       }
       if (nev + 2 > (int)W.ev.size()) throw std::runtime_error("too many search launches in one batch");
       HIP_CHECK(hipEventRecord(W.ev[nev], st));
+      if (with_big) {  // first, so that its few workgroups are resident before the ordinary launch fills the CUs
+        HIP_CHECK(hipStreamWaitEvent(I.side_stream, W.ev[nev], 0));
+        if (launch_search(big, big_lc, I.side_stream)) throw HipError(std::string("k_search (big): ") + launch_last_error());
+        HIP_CHECK(hipEventRecord(W.ev_side, I.side_stream));
+      }
       if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
+      if (with_big) HIP_CHECK(hipStreamWaitEvent(st, W.ev_side, 0));
       HIP_CHECK(hipEventRecord(W.ev[nev + 1], st));
       timed.emplace_back(nev, nev + 1);
       nev += 2;

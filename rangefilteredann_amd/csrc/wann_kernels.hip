@@ -46,57 +46,45 @@ __device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:
   return e < 10 ? 10 : e;
 }
 
-template <int METRIC>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A) {  // 2 waves per SIMD: at most 256 VGPRs
+// BIG = false: the ordinary kernel (four independent waves per workgroup, each with its own LDS slice).
+// BIG = true : the companion launch for speculative levels beyond cap_inkernel: ONE wave per workgroup that
+// owns a large LDS pool (beams up to big_cap), runs concurrently with the ordinary kernel on a second stream,
+// serves the static big list (longest class first) and then -- in its first npollers workgroups -- waits for
+// continuations handed over by ordinary waves until every ordinary ticket is done.  Two kernels rather than
+// two modes of one: the mode logic cost the ordinary kernel 20 VGPRs (it needs all 256 of two waves per SIMD).
+template <int METRIC, bool BIG>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
-  const int slot = blockIdx.x * (blockDim.x >> 6) + wib;  // 4 waves per workgroup, 1 for the large-beam follow-up launch
+  const int slot = blockIdx.x * (blockDim.x >> 6) + wib;  // 4 waves per workgroup, 1 for the large-beam launches
   const int per_wave = wave_lds_common_bytes(ix.stride) + A.pool_bytes;
   unsigned char *base = smem + (size_t)wib * per_wave;
   u64 *gbeam = A.g_beam ? A.g_beam + (size_t)slot * A.g_beam_cap : nullptr;
-  int32_t *gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
+  int32_t *const gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
   const int heavy = A.heavy_count ? *A.heavy_count : 0;
-  const int total = heavy + *A.list_count;
-  // per-mode parameters (wave-uniform): ordinary = one of four independent waves with its own LDS slice;
-  // big = wave 0 of one of the first nbig_blocks workgroups with the whole workgroup's LDS
-  int pool_bytes = A.pool_bytes, cap = A.cap_inkernel;
-  bool big = (int)blockIdx.x < A.nbig_blocks;
-  int big_total = 0, big_first = 0;
-  if (big) {
-    big_first = A.big_count[0];
-    big_total = big_first + A.big_count[1];
-    if (wib != 0) {  // waves 1-3 sleep at the barrier until wave 0 has drained the big list
-      __syncthreads();
-      big = false;
-    } else {
-      pool_bytes = per_wave * (int)(blockDim.x >> 6) - wave_lds_common_bytes(ix.stride);
-      cap = A.big_cap;
-      gtable = A.g_table_big + ((size_t)blockIdx.x << A.g_table_big_bits);
-    }
+  const int total = heavy + *A.list_count;  // ordinary tickets
+  const int pool_bytes = A.pool_bytes, cap = A.cap_inkernel;
+  // BIG: the first npollers workgroups only serve continuations, so that one starts as soon as it is handed over
+  bool polling = BIG && (int)blockIdx.x < A.npollers;
+  if (BIG && polling && A.big_count[0] + A.big_count[1] == 0) return;  // (pollers only in batches that have big levels at all)
+  // ordinary launch with a companion: as many ordinary workgroups as there are big items (+ pollers) leave at once, so that
+  // the companion's workgroups (launched first, but the LDS of every CU is fully booked by this launch) find room
+  if (!BIG && A.yield_for_big) {
+    const int items = A.big_count[0] + A.big_count[1];
+    if (items > 0 && (int)blockIdx.x < min(items + A.npollers, (int)gridDim.x / 2)) return;
   }
 
-  bool poll = false;  // big mode, static list drained: serving continuations
   for (;;) {
     int ti;
     bool dyn = false;
-    if (big && !poll) {
+    if (BIG && !polling) {
+      const int big_first = A.big_count[0], big_total = big_first + A.big_count[1];
       const int t = wave_ticket(A.big_cursor);
-      if (t >= big_total) {
-        if ((int)blockIdx.x < A.npollers && big_total > 0) {  // (pollers only in batches that have big levels at all)
-          poll = true;
-          continue;
-        }
-        __syncthreads();  // back to four ordinary waves
-        big = false;
-        pool_bytes = A.pool_bytes;
-        cap = A.cap_inkernel;
-        gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
-        continue;
-      }
+      if (t >= big_total) break;
       ti = (t < big_first) ? A.big_list[t] : A.big_list[A.big_stride + t - big_first];
-    } else if (big) {
+    } else if (BIG) {
       // wait for continuation number d, or for the end of all ordinary work (a producer publishes its item
       // before it reports its ticket done, so the item count is final once done_count == total)
       const int d = wave_ticket(A.dyn_cursor);
@@ -113,15 +101,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
         if (item >= 0 || (uni(fin) && !uni(have))) break;
         __builtin_amdgcn_s_sleep(32);
       }
-      if (item < 0) {  // nothing more can arrive
-        __syncthreads();
-        big = false;
-        poll = false;
-        pool_bytes = A.pool_bytes;
-        cap = A.cap_inkernel;
-        gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
-        continue;
-      }
+      if (item < 0) break;  // nothing more can arrive
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer's writes (next_beam) before its publication
       ti = item;
       dyn = true;
@@ -130,7 +110,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       if (t >= total) break;
       ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
     }
-    const bool ordinary_ticket = !big;
     Task task = A.tasks[ti];
     const PartDesc part = ix.parts[task.part];
     const int64_t qrow = task.query;
@@ -140,7 +119,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
     long long b = A.B;
     bool final_pass = A.is_final != 0;
     bool sub = (task.flags & 4) != 0;  // speculative sub-task: ONE search at beam B << level
-    if (dyn) {  // a continuation: a plain task or a resolved parent, at the beam its producer recorded
+    if (BIG && dyn) {  // a continuation: a plain task or a resolved parent, at the beam its producer recorded
       sub = false;
       b = __hip_atomic_load(A.next_beam + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (sub) b = (long long)A.B << (int)task.a;
@@ -157,7 +136,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       WAVE_SYNC();
       int m;
       long long nvis, ncmp;
+#ifdef WANN_TASK_TRACE
       const long long trace_t0 = A.trace ? (long long)wall_clock64() : 0;
+#endif
       if (table_lds && B <= 64 && !A.force_general)
         wave_beam_search_small<METRIC, 1>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
       else if (table_lds && B <= 128 && !A.force_general)
@@ -181,13 +162,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
         wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
                                                       nullptr, 0, m, nvis, ncmp, A.prof);
       auto beam_ld = [&](int i) -> u64 { return beam_lds ? L.lbeam[i] : gbeam[i]; };
+#ifdef WANN_TASK_TRACE
       if (A.trace && lane == 0) {
         long long *rec = A.trace + 1 + 4 * atomicAdd((unsigned long long *)A.trace, 1ull);
-        rec[0] = ti | (sub ? 1ll << 40 : 0) | (big ? 1ll << 41 : 0);
+        rec[0] = ti | (sub ? 1ll << 40 : 0) | (BIG ? 1ll << 41 : 0);
         rec[1] = B;
         rec[2] = trace_t0;
         rec[3] = (long long)wall_clock64();
       }
+#endif
       if (lane == 0) {
         if (sub) {  // attributed when the parent is resolved
           A.sub_hops[ti] = nvis;
@@ -308,7 +291,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       if (nb > cap) {
         if (lane == 0) {
           if (A.next_beam) A.next_beam[ti] = (int32_t)nb;
-          if (A.npollers > 0 && nb <= A.big_cap && A.big_count[0] + A.big_count[1] > 0) {  // to a poller of this launch
+          if (!BIG && A.npollers > 0 && nb <= A.big_cap && A.big_count[0] + A.big_count[1] > 0) {  // to a poller of the companion launch
             __threadfence();
             const int d = atomicAdd(A.dyn_count, 1);
             __hip_atomic_store(A.dyn_list + d, ti, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -320,7 +303,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       }
       b = nb;
     }
-    if (ordinary_ticket && A.done_count) {
+    if (!BIG && A.done_count) {
       WAVE_SYNC();
       // relaxed: a continuation is published by an atomic whose result this wave has already waited for, so it
       // is counted in dyn_count before this ticket is counted as done; no cache write-back per ticket
@@ -859,24 +842,23 @@ int launch_route(const RouteArgs &a, void *stream) {
   return check(hipGetLastError());
 }
 
+template <int METRIC, bool BIG>
+static int launch_search_t(const SearchArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  auto kern = k_search<METRIC, BIG>;
+  if (lds > 48 * 1024)
+    if (check(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return 1;
+  hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+  return check(hipGetLastError());
+}
+
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream) {
   if (cfg.blocks <= 0) return 0;
   const int wpb = cfg.waves_per_block > 0 ? cfg.waves_per_block : kWavesPerBlock;
   size_t lds = (size_t)search_lds_bytes_per_wave(a.ix.stride, a.pool_bytes) * wpb;
   dim3 grid(cfg.blocks), block(64 * wpb);
   hipStream_t s = (hipStream_t)stream;
-  if (a.ix.metric == 1) {
-    auto kern = k_search<1>;
-    if (lds > 48 * 1024)
-      if (check(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return 1;
-    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
-  } else {
-    auto kern = k_search<0>;
-    if (lds > 48 * 1024)
-      if (check(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return 1;
-    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
-  }
-  return check(hipGetLastError());
+  if (cfg.big) return a.ix.metric == 1 ? launch_search_t<1, true>(a, grid, block, lds, s) : launch_search_t<0, true>(a, grid, block, lds, s);
+  return a.ix.metric == 1 ? launch_search_t<1, false>(a, grid, block, lds, s) : launch_search_t<0, false>(a, grid, block, lds, s);
 }
 
 int launch_brute(const BruteArgs &a, int blocks, void *stream) {

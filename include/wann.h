@@ -95,7 +95,8 @@ const char *wann_last_error(void);
 int wann_device_count(void);
 
 /* Build (or load from the graph cache) an index and make it resident in the HBM of `device`.
- * points: (n,d) row-major of `dtype`; labels: (n) float32.  cutoff / split_factor /
+ * points: (n,d) row-major of `dtype` (uint8 / int8 sets: d <= 258, or 1024 for int8 inner products -- the
+ * range in which the reference's int32 arithmetic is reproduced exactly; device rows are fp32); labels: (n) float32.  cutoff / split_factor /
  * shift_factor as in the reference constructors (ignored by kinds that have none).
  * build_threads <= 0: PARLAY_NUM_THREADS if set, else all host cores. */
 wann_index *wann_index_create(int kind, int metric, int dtype, const void *points, int64_t n,
@@ -104,14 +105,15 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
                               int build_threads);
 void wann_index_destroy(wann_index *index);
 
-/* Host-buffer call (the reference's boundary: numpy in, numpy out).  ranges = nq x 2 float32
+/* Host-buffer call (the reference's boundary: numpy in, numpy out).  queries: (nq,d) of the index's dtype.  ranges = nq x 2 float32
  * (lo, hi), bounds inclusive (range_filter_tree.h:61).  method: "optimized_postfilter",
  * "three_split", anything else = fenwick (range_filter_tree.h:76-82); ignored by non-tree kinds.
  * ids: nq x k uint32, dists: nq x k float32, caller allocated. */
 int wann_batch_search(wann_index *index, const void *queries, const float *ranges, int64_t nq,
                       const char *method, const wann_query_params *qp, uint32_t *ids, float *dists);
 
-/* Device-buffer call: same semantics, every pointer is device memory on the index's device;
+/* Device-buffer call: same semantics, every pointer is device memory on the index's device (queries are fp32
+ * rows also for uint8 / int8 indexes);
  * `query_id_base` is the global row number of queries[0] (the reference uses the query's row
  * number as its "own id", beamSearch.h:128 + range_filter_tree.h:71-72, so a query shard must
  * keep its global numbering).  Runs on `hip_stream` (a hipStream_t; NULL = the HIP default stream,

@@ -205,21 +205,33 @@ class _Index:
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.n,)).copy()
 
 
-def _mk(kind, metric, tree_method):
+def _mk(kind, metric, tree_method, elem=None):
+    """elem = np.uint8 / np.int8: the reference's byte variants (euclidian_point.h:44-60, mips_point.h:44-58
+    accumulate in int32 and cast to float).  Points and queries are cast to the element type as pybind's
+    py::array_t<T> does, then restated with integer-valued fp32 rows -- exact while d * max_term < 2^24."""
+    def cast(a):
+        if elem is None:
+            return a
+        a = np.asarray(a).astype(elem)
+        bound = 128 * 128 if (elem is np.int8 and metric == MIPS) else 255 * 255
+        if a.shape[-1] * bound >= 1 << 24:
+            raise RuntimeError("byte variants are restated exactly up to 258 dimensions only")
+        return a.astype(np.float32)
+
     class K(_Index):
         KIND = kind
 
         def __init__(self, points, filter_values=None, cutoff=1000, split_factor=2,
                      shift_factor=0.5, build_params=None, filters=None, threads=None):
             lab = filter_values if filter_values is not None else filters
-            super().__init__(metric, points, lab, cutoff, split_factor, shift_factor, build_params, threads)
+            super().__init__(metric, cast(points), lab, cutoff, split_factor, shift_factor, build_params, threads)
 
         if tree_method:
             def batch_search(self, queries, filters, num_queries, query_method, query_params):
-                return self._search(queries, filters, num_queries, query_method, query_params)
+                return self._search(cast(queries), filters, num_queries, query_method, query_params)
         else:
             def batch_search(self, queries, filters, num_queries, query_params):
-                return self._search(queries, filters, num_queries, "", query_params)
+                return self._search(cast(queries), filters, num_queries, "", query_params)
     return K
 
 
@@ -233,6 +245,13 @@ VamanaRangeFilterTreeIndexFloatEuclidian = _mk(TREE_VAMANA, L2, True)
 VamanaRangeFilterTreeIndexFloatMips = _mk(TREE_VAMANA, MIPS, True)
 SuperOptimizedPostfilterTreeIndexFloatEuclidian = _mk(SUPER, L2, False)
 SuperOptimizedPostfilterTreeIndexFloatMips = _mk(SUPER, MIPS, False)
+for _en, _et in (("UInt8", np.uint8), ("Int8", np.int8)):
+    for _mn, _mc in (("Euclidian", L2), ("Mips", MIPS)):
+        globals()[f"PrefilterIndex{_en}{_mn}"] = _mk(PREFILTER, _mc, False, _et)
+        globals()[f"PostfilterVamanaIndex{_en}{_mn}"] = _mk(POSTFILTER, _mc, False, _et)
+        globals()[f"RangeFilterTreeIndex{_en}{_mn}"] = _mk(TREE_PREFILTER, _mc, True, _et)
+        globals()[f"VamanaRangeFilterTreeIndex{_en}{_mn}"] = _mk(TREE_VAMANA, _mc, True, _et)
+        globals()[f"SuperOptimizedPostfilterTreeIndex{_en}{_mn}"] = _mk(SUPER, _mc, False, _et)
 
 
 # ----------------------------------------------------------------------------- raw pieces

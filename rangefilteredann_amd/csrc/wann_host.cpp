@@ -119,6 +119,7 @@ struct Workspace {
 struct wann_index {
   HostIndex H;
   int device = 0;
+  int dtype = WANN_DTYPE_F32;  // element type of the caller's points / host queries (device rows are fp32)
   int num_cus = 256;
   DevBuf<float> d_points, d_labels, d_fv;
   DevBuf<uint32_t> d_decoding;
@@ -762,6 +763,18 @@ void build_pending(wann_index &I, std::vector<HostPart *> &pending) {
   save_built_graphs(H, pending, true);
 }
 
+std::vector<float> bytes_to_float(int dtype, const void *src, int64_t count) {
+  std::vector<float> out((size_t)count);
+  if (dtype == WANN_DTYPE_U8) {
+    const uint8_t *p = (const uint8_t *)src;
+    for (int64_t i = 0; i < count; i++) out[(size_t)i] = (float)p[i];
+  } else {
+    const int8_t *p = (const int8_t *)src;
+    for (int64_t i = 0; i < count; i++) out[(size_t)i] = (float)p[i];
+  }
+  return out;
+}
+
 BuildSpec make_spec(int kind, int metric, int64_t n, int64_t d, int32_t cutoff, double split_factor,
                     double shift_factor, const wann_build_params *bp, int threads) {
   BuildSpec s;
@@ -791,8 +804,8 @@ int wann_device_count(void) { return usable_devices(); }
 wann_index *wann_index_create(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
                               const float *labels, int32_t cutoff, double split_factor, double shift_factor,
                               const wann_build_params *bp, int device, int build_threads) {
-  if (dtype != WANN_DTYPE_F32) {
-    fail(WANN_ERR_UNSUPPORTED, "only float32 points are supported on the device path");
+  if (dtype != WANN_DTYPE_F32 && dtype != WANN_DTYPE_U8 && dtype != WANN_DTYPE_I8) {
+    fail(WANN_ERR_INVALID, "unknown dtype");
     return nullptr;
   }
   if (kind < 0 || kind > 4 || (metric != 0 && metric != 1) || !points || !labels || n <= 0 || d <= 0) {
@@ -803,13 +816,30 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
     fail(WANN_ERR_UNSUPPORTED, "point sets of 2^31 or more rows are not supported");
     return nullptr;
   }
+  // uint8 / int8 point sets (euclidian_point.h:44-60, mips_point.h:44-58: int32 accumulation, cast to float):
+  // the bytes become integer-valued fp32 rows; every partial sum then stays below 2^24, where fp32 arithmetic is
+  // exact in any order, so the fp32 kernels return exactly the reference's (float)int32 distances.
+  if (dtype != WANN_DTYPE_F32) {
+    const int64_t term = (metric == WANN_METRIC_MIPS && dtype == WANN_DTYPE_I8) ? 128 * 128 : 255 * 255;
+    if (d * term >= ((int64_t)1 << 24)) {
+      fail(WANN_ERR_UNSUPPORTED, "uint8/int8 point sets are supported up to 258 dimensions (1024 for int8 inner products): beyond "
+                                 "that fp32 accumulation is no longer exact");
+      return nullptr;
+    }
+  }
   if (usable_devices() <= device || device < 0) {
     fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
     return nullptr;
   }
+  std::vector<float> as_float;
+  if (dtype != WANN_DTYPE_F32) {
+    as_float = bytes_to_float(dtype, points, n * d);
+    points = as_float.data();
+  }
   std::unique_ptr<wann_index> I(new wann_index);
   try {
     I->device = device;
+    I->dtype = dtype;
     I->H.spec = make_spec(kind, metric, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
     std::vector<HostPart *> pending;
     build_host_index(I->H, (const float *)points, labels, -1, 0, &pending);
@@ -860,6 +890,11 @@ int wann_batch_search(wann_index *I, const void *queries, const float *ranges, i
     W.id_stage.ensure((size_t)nq * qp->k);
     W.dist_stage.ensure((size_t)nq * qp->k);
     hipStream_t st = I->own_stream;
+    std::vector<float> qf;  // host queries arrive in the index's element type
+    if (nq && I->dtype != WANN_DTYPE_F32) {
+      qf = bytes_to_float(I->dtype, queries, nq * d);
+      queries = qf.data();
+    }
     if (nq) {
       HIP_CHECK(hipMemcpyAsync(W.q_stage.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, st));
       HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
@@ -912,7 +947,13 @@ int64_t wann_device_bytes(const wann_index *I) { return I ? I->device_bytes : -1
 int wann_build_cache_shard(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
                            const float *labels, int32_t cutoff, double split_factor, double shift_factor,
                            const wann_build_params *bp, int shard, int nshards, int build_threads) {
-  if (dtype != WANN_DTYPE_F32) return fail(WANN_ERR_UNSUPPORTED, "only float32 points are supported");
+  std::vector<float> as_float;
+  if (dtype == WANN_DTYPE_U8 || dtype == WANN_DTYPE_I8) {
+    as_float = bytes_to_float(dtype, points, n * d);
+    points = as_float.data();
+  } else if (dtype != WANN_DTYPE_F32) {
+    return fail(WANN_ERR_INVALID, "unknown dtype");
+  }
   if (!bp || !bp->cache_path || !*bp->cache_path) return fail(WANN_ERR_INVALID, "cache_path required");
   if (nshards <= 0 || shard < 0 || shard >= nshards) return fail(WANN_ERR_INVALID, "bad shard");
   try {

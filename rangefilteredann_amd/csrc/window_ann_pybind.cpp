@@ -60,17 +60,18 @@ class Index {
  public:
   Index(int kind, int metric, int dtype, py::array points, FArray labels, int32_t cutoff, double split,
         double shift, const BuildParams &bp)
-      : kind_(kind) {
-    if (dtype != WANN_DTYPE_F32)
-      throw std::runtime_error("uint8/int8 point sets are not implemented on the MI355X path (float only)");
-    FArray pts = FArray::ensure(points);
-    if (!pts) throw std::runtime_error("points must be convertible to a float32 array");
+      : kind_(kind), dtype_(dtype) {
+    // py::array_t<T> semantics of the reference (python_bindings.cpp:113,121,...): any array is cast to T
+    py::array pts = dtype == WANN_DTYPE_F32 ? py::array(FArray::ensure(points))
+                  : dtype == WANN_DTYPE_U8 ? py::array(py::array_t<uint8_t, py::array::c_style | py::array::forcecast>::ensure(points))
+                                           : py::array(py::array_t<int8_t, py::array::c_style | py::array::forcecast>::ensure(points));
+    if (!pts) throw std::runtime_error("points must be convertible to an array of the index's element type");
     if (pts.ndim() != 2) throw std::runtime_error("points numpy array must be 2-dimensional");           // tree_utils.h:46
     if (labels.ndim() != 1) throw std::runtime_error("filter data numpy array must be 1-dimensional");    // tree_utils.h:53
     if (labels.shape(0) != pts.shape(0))
       throw std::runtime_error("filter data numpy array must have the same number of elements as the points array");
     wann_build_params wb{bp.max_degree, bp.limit, bp.alpha, bp.cache_path.c_str()};
-    const float *pp = pts.data();
+    const void *pp = pts.data();
     const float *lp = labels.data();
     int64_t n = pts.shape(0), d = pts.shape(1);
     {
@@ -91,18 +92,22 @@ class Index {
     return 0;
   }
 
-  NeighborsAndDistances search(FArray &queries, py::object filters, uint64_t nq, const std::string &method,
+  NeighborsAndDistances search(py::array queries_in, py::object filters, uint64_t nq, const std::string &method,
                                const QueryParams &qp) {
     FArray fr = FArray::ensure(filters);
     if (!fr) throw std::runtime_error("filters must be a sequence of (lo, hi) pairs");
     if (fr.ndim() != 2 || fr.shape(1) != 2 || (uint64_t)fr.shape(0) < nq)
       throw std::runtime_error("filters must have shape (num_queries, 2)");
+    py::array queries = dtype_ == WANN_DTYPE_F32 ? py::array(FArray::ensure(queries_in))
+                      : dtype_ == WANN_DTYPE_U8 ? py::array(py::array_t<uint8_t, py::array::c_style | py::array::forcecast>::ensure(queries_in))
+                                                : py::array(py::array_t<int8_t, py::array::c_style | py::array::forcecast>::ensure(queries_in));
+    if (!queries) throw std::runtime_error("queries must be convertible to an array of the index's element type");
     if (queries.ndim() != 2 || (uint64_t)queries.shape(0) < nq || queries.shape(1) != wann_dim(h_))
       throw std::runtime_error("queries must have shape (num_queries, dimension)");
     size_t k = (size_t)qp.c.k;
     py::array_t<unsigned int> ids({(size_t)nq, k});
     py::array_t<float> dists({(size_t)nq, k});
-    const float *qptr = queries.data();
+    const void *qptr = queries.data();
     const float *rptr = fr.data();
     unsigned int *ip = ids.mutable_data();
     float *dp = dists.mutable_data();
@@ -166,7 +171,7 @@ class Index {
   int64_t dim() const { return wann_dim(h_); }
 
  private:
-  int kind_;
+  int kind_, dtype_;
   wann_index *h_ = nullptr;
 };
 
@@ -198,7 +203,7 @@ static void add_variant(py::module_ &m, const std::string &agnostic) {
           }),
           "points"_a, "filter_values"_a, "build_params"_a = default_build_params())
         .def("batch_search",
-             [](C &self, FArray &q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
+             [](C &self, py::array q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
              "queries"_a, "filters"_a, "num_queries"_a, "query_params"_a);
     common_defs(c);
   }
@@ -211,7 +216,7 @@ static void add_variant(py::module_ &m, const std::string &agnostic) {
           "points"_a, "filter_values"_a, "cutoff"_a = 1000, "split_factor"_a = 2,
           "build_params"_a = default_build_params())
         .def("batch_search",
-             [](C &self, FArray &q, py::object f, uint64_t nq, const std::string &method, const QueryParams &qp) {
+             [](C &self, py::array q, py::object f, uint64_t nq, const std::string &method, const QueryParams &qp) {
                return self.search(q, f, nq, method, qp);
              },
              "queries"_a, "filters"_a, "num_queries"_a, "query_method"_a, "query_params"_a);
@@ -225,7 +230,7 @@ static void add_variant(py::module_ &m, const std::string &agnostic) {
           }),
           "points"_a, "filters"_a, "build_params"_a = default_build_params())
         .def("batch_search",
-             [](C &self, FArray &q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
+             [](C &self, py::array q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
              "queries"_a, "filters"_a, "num_queries"_a, "query_params"_a);
     common_defs(c);
   }
@@ -238,7 +243,7 @@ static void add_variant(py::module_ &m, const std::string &agnostic) {
           "points"_a, "filter_values"_a, "cutoff"_a = 1000, "split_factor"_a = 2,
           "build_params"_a = default_build_params())
         .def("batch_search",
-             [](C &self, FArray &q, py::object f, uint64_t nq, const std::string &method, const QueryParams &qp) {
+             [](C &self, py::array q, py::object f, uint64_t nq, const std::string &method, const QueryParams &qp) {
                return self.search(q, f, nq, method, qp);
              },
              "queries"_a, "filters"_a, "num_queries"_a, "query_method"_a, "query_params"_a);
@@ -253,7 +258,7 @@ static void add_variant(py::module_ &m, const std::string &agnostic) {
           "points"_a, "filter_values"_a, "cutoff"_a = 1000, "split_factor"_a = 2, "shift_factor"_a = 0.5,
           "build_params"_a = default_build_params())
         .def("batch_search",
-             [](C &self, FArray &q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
+             [](C &self, py::array q, py::object f, uint64_t nq, const QueryParams &qp) { return self.search(q, f, nq, "", qp); },
              "queries"_a, "filters"_a, "num_queries"_a, "query_params"_a);
     common_defs(c);
   }

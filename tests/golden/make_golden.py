@@ -30,10 +30,10 @@ def qp(ref, beam, mult, max_beam=10000, ratio=None):
     return ref.QueryParams(K, beam, 1.35, 10_000_000, 10_000, mult, max_beam, ratio, False)
 
 
-def make(name, metric, X, Q, labels, R, L, cutoff):
+def make(name, metric, X, Q, labels, R, L, cutoff, elem="Float"):
     ref = orc.load_reference(prefer=("native",))
     assert ref is not None, "build the reference first: make -C oracle ref REF_MARCH=native"
-    sfx = "FloatMips" if metric == "mips" else "FloatEuclidian"
+    sfx = elem + ("Mips" if metric == "mips" else "Euclidian")
     nq = Q.shape[0]
     tmp = tempfile.mkdtemp(prefix="golden_")
     out = {"X": X, "Q": Q, "labels": labels, "meta": np.array([R, L, cutoff, K], dtype=np.int64)}
@@ -90,9 +90,21 @@ def make(name, metric, X, Q, labels, R, L, cutoff):
 
 
 if __name__ == "__main__":
+    ONLY = set(sys.argv[1:])
+    _make = make
+
+    def make(name, *a, **k):  # noqa: F811  (python make_golden.py u8_l2 i8_mips: regenerate only these)
+        if not ONLY or name in ONLY:
+            _make(name, *a, **k)
     n, d, nq = 2048, 32, 48
     g = sift_like(n, d, 1234)
     make("sift_l2", "Euclidian", g(n), g(nq), distinct_labels(n, 7), R=16, L=32, cutoff=200)
     n, d = 1536, 100
     g = unit_mixture(n, d, 99)
     make("unit_mips", "mips", g(n), g(nq), distinct_labels(n, 8), R=16, L=32, cutoff=200)
+    # byte variants (python_bindings.cpp:234-237; int32 distances cast to float, euclidian_point.h:44-60, mips_point.h:44-58)
+    n, d, nq = 1024, 24, 32
+    g = sift_like(n, d, 4321)
+    make("u8_l2", "Euclidian", g(n).astype(np.uint8), g(nq).astype(np.uint8), distinct_labels(n, 9), R=16, L=32, cutoff=200, elem="UInt8")
+    g = sift_like(n, d, 8765)
+    make("i8_mips", "mips", (g(n) - 128).astype(np.int8), (g(nq) - 128).astype(np.int8), distinct_labels(n, 10), R=16, L=32, cutoff=200, elem="Int8")

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = {"sift_l2": "FloatEuclidian", "unit_mips": "FloatMips"}
+FIXTURES = {"sift_l2": "FloatEuclidian", "unit_mips": "FloatMips", "u8_l2": "UInt8Euclidian", "i8_mips": "Int8Mips"}
 KINDS = {
     "VamanaRangeFilterTreeIndex": dict(split_factor=2),
     "SuperOptimizedPostfilterTreeIndex": dict(split_factor=2, shift_factor=0.5),

@@ -51,10 +51,19 @@ def test_no_gpu_means_loud_failure(wa):
         wa.raw_beam_search(0, X, np.zeros((16, 5), dtype=np.int32), 0, X[:2], np.arange(2), 4)
 
 
-def test_uint8_variants_raise(wa):
-    X = np.zeros((16, 8), dtype=np.uint8)
-    with pytest.raises(RuntimeError, match="float only"):
-        wa.VamanaRangeFilterTreeIndexUInt8Euclidian(X, np.arange(16, dtype=np.float32))
+def test_byte_variants_are_bounded_by_exactness(wa):
+    """uint8 / int8 classes (python_bindings.cpp:234-237) run as integer-valued fp32 rows: accepted while the
+    reference's int32 distance is reproduced exactly (d * max_term < 2^24), refused beyond."""
+    lab = np.arange(16, dtype=np.float32)
+    with pytest.raises(RuntimeError, match="258 dimensions"):
+        wa.VamanaRangeFilterTreeIndexUInt8Euclidian(np.zeros((16, 300), dtype=np.uint8), lab)
+    with pytest.raises(RuntimeError, match="258 dimensions"):
+        wa.PrefilterIndexInt8Euclidian(np.zeros((16, 300), dtype=np.int8), lab)
+    if wa.device_count() == 0:  # within the bound only the missing device stops the construction
+        with pytest.raises(RuntimeError, match="no usable gfx950 device"):
+            wa.PrefilterIndexInt8Mips(np.zeros((16, 300), dtype=np.int8), lab)
+        with pytest.raises(RuntimeError, match="no usable gfx950 device"):
+            wa.SuperOptimizedPostfilterTreeIndexUInt8Mips(np.zeros((16, 8), dtype=np.uint8), lab)
 
 
 def test_engine_kernels_use_no_scratch(wa, tmp_path):

@@ -65,6 +65,7 @@ struct Counters {
   // searches run speculatively at beams beyond the one the sequential loop stops at (extra work,
   // not part of the reference's operation count)
   unsigned long long spec_searches, spec_hops, spec_dist_cmps;
+  unsigned long long poll_timeouts;  // a poller gave up waiting (never expected: the host turns it into an error)
 };
 
 struct RouteArgs {

@@ -720,6 +720,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.spec_hops = (int64_t)W.h_ctr->spec_hops;
   I.last.spec_dist_cmps = (int64_t)W.h_ctr->spec_dist_cmps;
   I.last.rounds = rounds;
+  if (W.h_ctr->poll_timeouts)
+    throw std::runtime_error("internal error: a continuation poller of the beam-search launch timed out; results may be incomplete");
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");

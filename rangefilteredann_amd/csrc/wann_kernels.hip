@@ -89,6 +89,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
       // before it reports its ticket done, so the item count is final once done_count == total)
       const int d = wave_ticket(A.dyn_cursor);
       int item = -1;
+      bool settled = false;
       for (int spin = 0; spin < (1 << 22); spin++) {
         int have = 0, fin = 0;
         if (lane == 0) {
@@ -98,9 +99,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
           if (have) item = __hip_atomic_load(A.dyn_list + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         item = uni(item);
-        if (item >= 0 || (uni(fin) && !uni(have))) break;
+        if (item >= 0 || (uni(fin) && !uni(have))) {
+          settled = true;
+          break;
+        }
         __builtin_amdgcn_s_sleep(32);
       }
+      if (!settled && lane == 0) atomicAdd(&A.ctr->poll_timeouts, 1ull);
       if (item < 0) break;  // nothing more can arrive
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer's writes (next_beam) before its publication
       ti = item;

@@ -36,8 +36,9 @@ namespace wann {
 //   small: beam + seen-filter          (4 << bits) + 8 B <= pool
 //   big  : beam only, filter in global (8 B <= pool)
 //   huge : nothing (beam and filter in per-slot global scratch)
-// Beams above A.cap_inkernel leave the kernel through next_list / final_list and are handled by
-// follow-up launches of this same kernel (A.is_round).
+// Beams above A.cap_inkernel leave the kernel: speculative levels were routed to the companion launch
+// (BIG = true) from the start, continuations go to its pollers, the rest (next_list / final_list) to
+// follow-up launches of this same kernel.
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:66
   long long sq = beam * beam;

@@ -27,6 +27,7 @@ CLI (same flags as the reference driver):
 from __future__ import annotations
 
 import argparse
+import csv
 import gc
 import os
 import resource
@@ -363,6 +364,69 @@ class Experiments:
         return everything
 
 
+# ----------------------------------------------------------------------------------------------------------
+# memory footprint (counterparts of experiments/all_memories.py and experiments/memory_footprint.py)
+# ----------------------------------------------------------------------------------------------------------
+MEMORY_INDEX_TYPES = ("postfiltering", "vamana-tree", "super-postfiltering")  # all_memories.py:108-118
+
+
+def natural_size(nbytes: int) -> str:
+    """humanize.naturalsize (decimal units, one decimal), which all_memories.py:39 applies to the RSS growth."""
+    v = float(nbytes)
+    if abs(v) < 1000:
+        return "%d Bytes" % v if v != 1 else "1 Byte"
+    for unit in ("kB", "MB", "GB", "TB", "PB"):
+        v /= 1000.0
+        if abs(v) < 1000 or unit == "PB":
+            return "%.1f %s" % (v, unit)
+    return "%.1f PB" % v
+
+
+def build_for_memory(index_type, data, filter_values, metric, dataset_name, alpha=1.0, split_factor=2, cache_root="index_cache"):
+    """Construct the index exactly as all_memories.py:25-83 does and return (index, bytes).  The reference reports the
+    growth of the process RSS (its index lives in host memory); this engine's index lives in HBM, so the figure is the
+    device footprint (`index.device_bytes()`: vectors + labels + decoding + adjacency pool + partition tables)."""
+    if index_type == "postfiltering":
+        cons, kw, sub = postfilter_vamana_constructor(metric, "float"), {}, f"{dataset_name}/unsorted-"
+    elif index_type == "vamana-tree":
+        cons, kw, sub = vamana_range_filter_tree_constructor(metric, "float"), dict(cutoff=1_000, split_factor=split_factor), f"{dataset_name}/"
+    elif index_type == "super-postfiltering":
+        cons, kw, sub = super_optimized_postfilter_tree_constructor(metric, "float"), dict(cutoff=1_000, split_factor=split_factor, shift_factor=0.5), f"{dataset_name}-super_opt_postfiltering/"
+    else:
+        raise ValueError("Invalid index type")  # all_memories.py:119-120
+    path = os.path.join(cache_root, sub)
+    os.makedirs(path if path.endswith("/") else os.path.dirname(path), exist_ok=True)
+    bp = BuildParams(64, 500, alpha, path)
+    index = cons(data, filter_values, build_params=bp, **kw) if kw else cons(data, filter_values, bp)
+    return index, int(index.device_bytes())
+
+
+def write_memory_csv(results_dir, file_name, headers, row):
+    """results/<file_name>, appended, header once (all_memories.py:86-98, memory_footprint.py:41-53)."""
+    os.makedirs(results_dir, exist_ok=True)
+    path = os.path.join(results_dir, file_name)
+    exists = os.path.isfile(path)
+    with open(path, "a", newline="") as f:
+        w = csv.writer(f)
+        if not exists:
+            w.writerow(headers)
+        w.writerow(row)
+    return path
+
+
+def memory_main(args):
+    data, _, filter_values, metric = initialize_dataset(args.dataset_folder, args.dataset)
+    if args.index_type:  # all_memories.py: method, dataset, humanised size
+        label = {"postfiltering": "postfiltering", "vamana-tree": "vamana-tree", "super-postfiltering": "super postfiltering"}
+        _, nbytes = build_for_memory(args.index_type, data, filter_values, metric, args.dataset, 1.0, 2)
+        print(write_memory_csv("results", "memory_usage.csv", ["method", "dataset", "memory"], [label[args.index_type], args.dataset, natural_size(nbytes)]))
+    else:  # memory_footprint.py: method, branching factor, KiB (ru_maxrss units)
+        b = args.vamana_tree_split_factor
+        _, nbytes = build_for_memory("vamana-tree", data, filter_values, metric, args.dataset, args.alpha if args.alpha is not None else 1.0, b)
+        print(write_memory_csv("results", "vamana_tree_memory_usage.csv", ["method", "branching_factor", "memory"], ["vamana-tree", b, nbytes // 1024]))
+    return 0
+
+
 ALL_METHODS = ("prefiltering", "postfiltering", "vamana_tree", "optimized_postfiltering", "smart_combined", "three_split",
                "super_opt_postfiltering")
 
@@ -387,9 +451,21 @@ def main(argv=None):
     ap.add_argument("--super_opt_postfiltering_shift_factor", type=float)
     ap.add_argument("--synthetic", type=str, default=None, metavar="N,D,NQ",
                     help="write a synthetic dataset of that shape into --dataset_folder first (no real data on this machine)")
+    ap.add_argument("--memory", action="store_true",
+                    help="index memory footprint instead of a search experiment: with --index_type {postfiltering,vamana-tree,"
+                         "super-postfiltering} as experiments/all_memories.py, else with --vamana_tree_split_factor as "
+                         "experiments/memory_footprint.py")
+    ap.add_argument("--index_type", type=str, default=None)
     args = ap.parse_args(argv)
     threads = args.threads or (os.cpu_count() or 1)
     os.environ["PARLAY_NUM_THREADS"] = str(threads)
+    if args.memory:
+        if not args.dataset or (not args.index_type and args.vamana_tree_split_factor is None):
+            ap.error("--memory needs --dataset and --index_type or --vamana_tree_split_factor")
+        if args.synthetic:
+            n, d, nq = (int(x) for x in args.synthetic.split(","))
+            write_synthetic_dataset(args.dataset_folder, args.dataset, n, d, nq, ["2pow-3"])
+        return memory_main(args)
     methods = ALL_METHODS if args.all_methods else tuple(m for m in ALL_METHODS if getattr(args, m))
     if not methods:
         print("NOTE: No experiments specified, so aborting")

@@ -100,3 +100,34 @@ def test_end_to_end_equals_oracle_driven_run(hz, oracle, wa, gpu, tmp_path, monk
     assert max(r[2] for r in got[(dataset, "2pow-3")] if r[1].startswith("optimized-postfiltering")) > 0.9
     text = open(os.path.join(str(tmp_path / "results_gpu"), f"{dataset}_results.csv")).read().splitlines()
     assert text[0] + "\n" == hz.RESULTS_HEADER and len(text) == 1 + sum(len(v) for v in got.values())
+
+
+def test_memory_footprint_tooling(hz, tmp_path, monkeypatch):
+    """Counterparts of experiments/all_memories.py / memory_footprint.py: humanize's size strings (decimal units, one
+    decimal), the index-type names, the CSV files (header once, rows appended) and the constructor arguments."""
+    assert [hz.natural_size(x) for x in (1, 999, 1000, 3_110_000_000, 22_700_000_000)] == ["1 Byte", "999 Bytes", "1.0 kB", "3.1 GB", "22.7 GB"]
+    assert hz.MEMORY_INDEX_TYPES == ("postfiltering", "vamana-tree", "super-postfiltering")
+    p = hz.write_memory_csv(str(tmp_path / "results"), "memory_usage.csv", ["method", "dataset", "memory"], ["vamana-tree", "sift-128-euclidean", "3.1 GB"])
+    hz.write_memory_csv(str(tmp_path / "results"), "memory_usage.csv", ["method", "dataset", "memory"], ["postfiltering", "sift-128-euclidean", "0.8 GB"])
+    assert open(p).read().splitlines() == ["method,dataset,memory", "vamana-tree,sift-128-euclidean,3.1 GB", "postfiltering,sift-128-euclidean,0.8 GB"]
+    seen = {}
+
+    class Fake:
+        def __init__(self, *a, **k):
+            seen["a"], seen["k"] = a, k
+
+        def device_bytes(self):
+            return 12345
+
+    monkeypatch.setattr(hz, "super_optimized_postfilter_tree_constructor", lambda m, t: Fake)
+    monkeypatch.setattr(hz, "postfilter_vamana_constructor", lambda m, t: Fake)
+    monkeypatch.setattr(hz, "BuildParams", lambda R, L, alpha, cache: type("BP", (), dict(R=R, L=L, alpha=alpha, cache_path=cache))())
+    monkeypatch.chdir(tmp_path)
+    _, nb = hz.build_for_memory("super-postfiltering", np.zeros((4, 2), np.float32), np.arange(4, dtype=np.float32), "Euclidian", "ds", 1.0, 2)
+    assert nb == 12345 and seen["k"]["cutoff"] == 1000 and seen["k"]["split_factor"] == 2 and seen["k"]["shift_factor"] == 0.5
+    bp = seen["k"]["build_params"]
+    assert (bp.R, bp.L, bp.alpha) == (64, 500, 1.0) and bp.cache_path.endswith("index_cache/ds-super_opt_postfiltering/")
+    hz.build_for_memory("postfiltering", np.zeros((4, 2), np.float32), np.arange(4, dtype=np.float32), "Euclidian", "ds")
+    assert len(seen["a"]) == 3 and seen["a"][2].cache_path.endswith("index_cache/ds/unsorted-")
+    with pytest.raises(ValueError, match="Invalid index type"):
+        hz.build_for_memory("ivf", None, None, "Euclidian", "ds")

@@ -171,41 +171,97 @@ __device__ __forceinline__ void l2_pair2_ct(const float *__restrict__ prow0, con
   d1 = (((other + clo.x) + clo.y) + chi.x) + chi.y;
 }
 
-// Negative inner product (mips_point.h:60-66 as compiled): running scalar, products rounded then
-// added in index order for the first 8*floor(d/8) elements, fused for the tail.  One lane per row.
-template <int NB>
-__device__ __forceinline__ float mips_lane(const float *__restrict__ prow, const float *qv, int d,
-                                           bool active) {
+// Negative inner product (mips_point.h:60-66 as compiled): ONE running scalar per candidate, products rounded
+// then added in index order for the first 8*floor(d/8) elements, fused multiply-adds for the tail.
+// A lane PAIR owns a candidate (like the L2 routine): lane h loads the float4s 2t+h of the row -- 32
+// contiguous bytes per pair and load instruction instead of 16 bytes from 64 different rows -- and multiplies
+// them by its part of the query; the chain of additions is the same in both lanes, each addend fetched from
+// the lane that holds it by a DPP quad permutation (no extra instruction, no LDS).  The order of the
+// additions is exactly the sequential one.
+template <bool ODD>
+__device__ __forceinline__ float pair_lane(float v) {  // the value lane 2c+ODD of my pair holds
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ODD ? 0xF5 : 0xA0, 0xF, 0xF, true));
+}
+
+// one pair step: float4 2t (even lane) and 2t+1 (odd lane) of row and query; `tail` = fused part (wave-uniform)
+__device__ __forceinline__ float mips_step(float r, const float4 &p, const float4 &q, bool tail) {
+  if (!tail) {
+    const float px = __fmul_rn(q.x, p.x), py = __fmul_rn(q.y, p.y), pz = __fmul_rn(q.z, p.z), pw = __fmul_rn(q.w, p.w);
+    r = __fadd_rn(r, pair_lane<false>(px));
+    r = __fadd_rn(r, pair_lane<false>(py));
+    r = __fadd_rn(r, pair_lane<false>(pz));
+    r = __fadd_rn(r, pair_lane<false>(pw));
+    r = __fadd_rn(r, pair_lane<true>(px));
+    r = __fadd_rn(r, pair_lane<true>(py));
+    r = __fadd_rn(r, pair_lane<true>(pz));
+    r = __fadd_rn(r, pair_lane<true>(pw));
+  } else {
+    r = fmaf(pair_lane<false>(q.x), pair_lane<false>(p.x), r);
+    r = fmaf(pair_lane<false>(q.y), pair_lane<false>(p.y), r);
+    r = fmaf(pair_lane<false>(q.z), pair_lane<false>(p.z), r);
+    r = fmaf(pair_lane<false>(q.w), pair_lane<false>(p.w), r);
+    r = fmaf(pair_lane<true>(q.x), pair_lane<true>(p.x), r);
+    r = fmaf(pair_lane<true>(q.y), pair_lane<true>(p.y), r);
+    r = fmaf(pair_lane<true>(q.z), pair_lane<true>(p.z), r);
+    r = fmaf(pair_lane<true>(q.w), pair_lane<true>(p.w), r);
+  }
+  return r;
+}
+
+// NP = pair steps (ceil(ceil(d/4) / 2)); rows and the staged query are zero padded to 16 floats, so a step may
+// run past d: the extra terms are +0 and leave the (never negative-zero) running sum unchanged.
+template <int NP>
+__device__ __forceinline__ float mips_pair_ct(const float *__restrict__ prow, const float *qv, int d, int h) {
+  const int tail_from = (d & ~7) >> 3;  // first fused step
+  float4 buf[NP];
+#pragma unroll
+  for (int t = 0; t < NP; t++) buf[t] = *reinterpret_cast<const float4 *>(prow + 8 * t + 4 * h);
   float r = 0.f;
-  if (active) {
-    const int nch = (d + 3) >> 2;
-    const int dv = d & ~7;
-    for (int c0 = 0; c0 < nch; c0 += NB) {
-      float4 buf[NB];
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        int c = c0 + j;
-        if (c < nch) buf[j] = *reinterpret_cast<const float4 *>(prow + 4 * c);
-      }
+  for (int t = 0; t < NP; t++) {
+    const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * t + 4 * h);
+    r = mips_step(r, buf[t], q, t >= tail_from);
+  }
+  return -r;
+}
+
+// two candidates per lane pair, every load of both rows in flight before the first use
+template <int NP>
+__device__ __forceinline__ void mips_pair2_ct(const float *__restrict__ prow0, const float *__restrict__ prow1,
+                                              const float *qv, int d, int h, float &d0, float &d1) {
+  const int tail_from = (d & ~7) >> 3;
+  float4 b0[NP], b1[NP];
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        int c = c0 + j;
-        if (c < nch) {
-          float4 q = *reinterpret_cast<const float4 *>(qv + 4 * c);
-          if (4 * c + 3 < dv) {
-            r = __fadd_rn(r, __fmul_rn(q.x, buf[j].x));
-            r = __fadd_rn(r, __fmul_rn(q.y, buf[j].y));
-            r = __fadd_rn(r, __fmul_rn(q.z, buf[j].z));
-            r = __fadd_rn(r, __fmul_rn(q.w, buf[j].w));
-          } else {  // dv is a multiple of 8, so a chunk is entirely vector part or entirely tail
-            r = fmaf(q.x, buf[j].x, r);
-            r = fmaf(q.y, buf[j].y, r);
-            r = fmaf(q.z, buf[j].z, r);
-            r = fmaf(q.w, buf[j].w, r);
-          }
-        }
+  for (int t = 0; t < NP; t++) b0[t] = *reinterpret_cast<const float4 *>(prow0 + 8 * t + 4 * h);
+#pragma unroll
+  for (int t = 0; t < NP; t++) b1[t] = *reinterpret_cast<const float4 *>(prow1 + 8 * t + 4 * h);
+  float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < NP; t++) {
+    const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * t + 4 * h);
+    const bool tail = t >= tail_from;
+    r0 = mips_step(r0, b0[t], q, tail);
+    r1 = mips_step(r1, b1[t], q, tail);
+  }
+  d0 = -r0;
+  d1 = -r1;
+}
+
+// any dimension: blocks of 8 pair steps
+__device__ __forceinline__ float mips_pair(const float *__restrict__ prow, const float *qv, int d, int h) {
+  const int np = (((d + 3) >> 2) + 1) >> 1, tail_from = (d & ~7) >> 3;
+  float r = 0.f;
+  for (int t0 = 0; t0 < np; t0 += 8) {
+    float4 buf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (t0 + j < np) buf[j] = *reinterpret_cast<const float4 *>(prow + 8 * (t0 + j) + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (t0 + j < np) {
+        const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * (t0 + j) + 4 * h);
+        r = mips_step(r, buf[j], q, t0 + j >= tail_from);
       }
-    }
   }
   return -r;
 }
@@ -232,11 +288,33 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
                                                 int64_t row_off) {
   const int lane = lane_id();
   if (METRIC == 1) {
-    bool act = lane < cnt;
-    int id = act ? ids_lds[lane] : 0;
-    const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
-    wave_touch_rows(ix, ids_lds, 0, cnt, row_off);  // one lane walks a whole row: get all its lines moving first
-    return mips_lane<8>(prow, qv, ix.d, act);
+    const int h = lane & 1;
+    const int np = (((ix.d + 3) >> 2) + 1) >> 1;  // wave-uniform
+    const int s0 = lane >> 1, s1 = 32 + (lane >> 1);
+    const bool act0 = s0 < cnt, act1 = s1 < cnt;
+    const int id0 = act0 ? ids_lds[s0] : 0, id1 = act1 ? ids_lds[s1] : 0;  // idle pairs score node 0: no branches
+    const float *p0 = ix.points + (row_off + id0) * (int64_t)ix.stride;
+    const float *p1 = ix.points + (row_off + id1) * (int64_t)ix.stride;
+    float d0, d1 = 0.f;
+    if (cnt > 32) {  // one round trip for up to 64 candidates
+      switch (np) {
+        case 12: mips_pair2_ct<12>(p0, p1, qv, ix.d, h, d0, d1); break;  // d = 96
+        case 13: mips_pair2_ct<13>(p0, p1, qv, ix.d, h, d0, d1); break;  // d = 100
+        default: d0 = mips_pair(p0, qv, ix.d, h); d1 = mips_pair(p1, qv, ix.d, h); break;
+      }
+      if (act1 && h) scratch_lds[s1] = d1;
+    } else {
+      switch (np) {
+        case 12: d0 = mips_pair_ct<12>(p0, qv, ix.d, h); break;
+        case 13: d0 = mips_pair_ct<13>(p0, qv, ix.d, h); break;
+        default: d0 = mips_pair(p0, qv, ix.d, h); break;
+      }
+    }
+    if (act0 && h) scratch_lds[s0] = d0;
+    WAVE_SYNC();
+    float r = (lane < cnt) ? scratch_lds[lane] : 0.f;
+    WAVE_SYNC();
+    return r;
   } else {
     const int D8 = (ix.d + 7) >> 3;
     const int h = lane & 1;

@@ -24,6 +24,10 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 CONFIGS = {
     "glove": dict(n=1_183_514, d=100, frac=-6, cls="SuperOptimizedPostfilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=2, shift_factor=0.5), method=None),
     "deep": dict(n=9_990_000, d=96, frac=-3, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=4), method="optimized_postfilter"),
+    # the other two query methods of the tree (range_filter_tree.h:297-401,473-540) at configs[1] size, unit-norm MIPS rows
+    # (continuous coordinates: no distance ties, so rows must match exactly although both sides sort unstably)
+    "fenwick": dict(n=1_000_000, d=100, frac=-6, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=2), method="fenwick"),
+    "three_split": dict(n=1_000_000, d=100, frac=-6, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=2), method="three_split"),
 }
 R, L, ALPHA, K = 64, 500, 1.0, 10
 
@@ -97,7 +101,7 @@ def main():
     t0 = time.time()
     X, Q, labels = make(cfg, n, nq)
     print(f"[cfg] {args.config}: data n={n} d={d} in {time.time() - t0:.1f}s; host {os.cpu_count()} cpus, {mem_gib:.0f} GiB", file=sys.stderr, flush=True)
-    cache = os.path.join(args.cache, f"{args.config}_n{n}") + "/"
+    cache = os.path.join(args.cache, f"{'tree1m' if args.config in ('fenwick', 'three_split') else args.config}_n{n}") + "/"
     os.makedirs(cache, exist_ok=True)
     t0 = time.time()
     index = getattr(wa, cfg["cls"])(X, labels, build_params=wa.BuildParams(R, L, ALPHA, cache), **cfg["kw"])

@@ -529,8 +529,9 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = part.start;
-  if (TABLE_LDS) {
-    for (int i = lane; i < (1 << bits); i += 64) L.ltable[i] = -1;
+  if (TABLE_LDS) {  // (16-byte aligned: carve_wave_lds)
+    int4 *lt = reinterpret_cast<int4 *>(L.ltable);
+    for (int i = lane; i < (1 << (bits - 2)); i += 64) lt[i] = make_int4(-1, -1, -1, -1);
   } else {
     int4 *gt = reinterpret_cast<int4 *>(gtable);
     for (int i = lane; i < (1 << (bits - 2)); i += 64) gt[i] = make_int4(-1, -1, -1, -1);
@@ -688,7 +689,10 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
   const uint32_t tmask = (1u << bits) - 1u;
   constexpr uint32_t TAG = 0x80000000u;
   const int64_t row_off = part.start;
-  for (int i = lane; i < (1 << bits); i += 64) L.ltable[i] = -1;
+  {  // (16-byte aligned: carve_wave_lds)
+    int4 *lt = reinterpret_cast<int4 *>(L.ltable);
+    for (int i = lane; i < (1 << (bits - 2)); i += 64) lt[i] = make_int4(-1, -1, -1, -1);
+  }
   if (lane == 0) L.cand_id[0] = 0;
   WAVE_SYNC();
   float d0 = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, 1, row_off);

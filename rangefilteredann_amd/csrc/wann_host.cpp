@@ -77,12 +77,14 @@ struct Workspace {
   int32_t *h_ints = nullptr;  // pinned
   Counters *h_ctr = nullptr;  // pinned
   std::vector<hipEvent_t> ev;
-  hipEvent_t ev_side = nullptr;  // end of the companion (big) launch on the index's side stream
+  hipEvent_t ev_side = nullptr;   // end of the companion (big) launch on the index's side stream
+  hipEvent_t ev_route = nullptr;  // list sizes of k_route are on the host
   ~Workspace() {
     if (h_ints) (void)hipHostFree(h_ints);
     if (h_ctr) (void)hipHostFree(h_ctr);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (ev_side) (void)hipEventDestroy(ev_side);
+    if (ev_route) (void)hipEventDestroy(ev_route);
   }
   void ensure(int64_t nq, int k, int maxt, int64_t sub_slots) {
     const size_t nt = (size_t)nq * maxt + (size_t)sub_slots;
@@ -106,6 +108,7 @@ struct Workspace {
     if (!h_ints) HIP_CHECK(hipHostMalloc((void **)&h_ints, kInts * sizeof(int32_t)));
     if (!h_ctr) HIP_CHECK(hipHostMalloc((void **)&h_ctr, sizeof(Counters)));
     if (!ev_side) HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    if (!ev_route) HIP_CHECK(hipEventCreateWithFlags(&ev_route, hipEventDisableTiming));
     while (ev.size() < 2 + 4 * kMaxRounds) {
       hipEvent_t e;
       HIP_CHECK(hipEventCreate(&e));
@@ -472,6 +475,13 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.big_stride = W.big_stride;
   ra.ctr = W.ctr.p;
   if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
+  // the list sizes come back while the exact scans run: the beam-search launches are sized by them, and skipped
+  // altogether for batches without graph tasks (tiny windows) / without levels beyond the in-kernel cap
+  const bool sized = I.H.vamana_leaves && qp.beam_width < qp.postfiltering_max_beam;
+  if (sized) {
+    HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(W.ev_route, st));
+  }
 
   if (I.H.spec.kind == WANN_KIND_PREFILTER && nq >= 32 && !getenv("WANN_NO_GEMM"))
     dense_prefilter(I, d_queries, nq, k, st);
@@ -495,7 +505,13 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
 
   int rounds = 0, nev = 2;
   std::vector<std::pair<int, int>> timed;  // event index pairs around search launches
-  if (I.H.vamana_leaves && qp.beam_width < qp.postfiltering_max_beam) {
+  int64_t graph_n = 0, big_n = 0;
+  if (sized) {
+    HIP_CHECK(hipEventSynchronize(W.ev_route));
+    graph_n = (int64_t)W.h_ints[I_GRAPH_COUNT] + W.h_ints[I_HEAVY_COUNT];
+    big_n = (int64_t)W.h_ints[I_BIG_COUNT] + W.h_ints[I_BIG_COUNT + 1];
+  }
+  if (sized && graph_n + big_n > 0) {
     SearchArgs sa{};
     sa.ix = I.view;
     sa.queries = d_queries;
@@ -605,7 +621,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.next_list = W.list_b.p;
     sa.next_count = W.ints.p + I_NEXT0;
     sa.final_count = W.ints.p + I_FINAL0;
-    launch(sa, b0, cap1, nq * (int64_t)std::min(maxt, 8) + (spec ? nq : 0), false, big_cap);
+    launch(sa, b0, cap1, graph_n, false, big_n > 0 ? big_cap : 0);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];

@@ -343,9 +343,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_brute(BruteArgs A) {
   u64 *top = reinterpret_cast<u64 *>(base + off);
   const int total = *A.list_count;
   const int step = (METRIC == 1) ? 64 : 64;
+  // scans are short and uniform: a wave takes four tickets at a time and reports its row count once (ten thousand
+  // same-address atomics per batch were most of a tiny-window batch)
+  constexpr int kTickets = 4;
+  unsigned long long rows_done = 0;
 
-  for (;;) {
-    const int t = wave_ticket(A.cursor);
+  for (int t = 0, tend = 0;; t++) {
+    if (t >= tend) {
+      int lane0;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane0));  // (see wave_ticket)
+      int tt = 0;
+      if (lane0 == 0) tt = atomicAdd(A.cursor, kTickets);
+      t = __builtin_amdgcn_readfirstlane(tt);
+      tend = t + kTickets;
+    }
     if (t >= total) break;
     const int ti = A.list[t];
     const Task task = A.tasks[ti];
@@ -371,12 +382,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_brute(BruteArgs A) {
       u64 e = top[x];
       A.out_key[(size_t)ti * K + x] = (e & 0xffffffff00000000ull) | (uint32_t)((uint32_t)e >> 1);
     }
-    if (lane == 0) {
-      A.out_cnt[ti] = m;
-      atomicAdd(&A.ctr->brute_rows, (unsigned long long)(task.b > task.a ? task.b - task.a : 0));
-    }
+    if (lane == 0) A.out_cnt[ti] = m;
+    rows_done += (unsigned long long)(task.b > task.a ? task.b - task.a : 0);
     WAVE_SYNC();
   }
+  if (lane == 0 && rows_done) atomicAdd(&A.ctr->brute_rows, rows_done);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -326,14 +326,37 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   std::vector<Task> tasks((size_t)nq);
   HIP_CHECK(hipMemcpyAsync(tasks.data(), W.tasks.p, (size_t)nq * sizeof(Task), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  // group the queries by window in O(nq): open-addressing table over (a, b), then a counting sort by group
+  // (a comparison sort of 10 000 queries cost 0.3 ms of a 1 ms batch); groups in first-seen order, members ascending
   std::vector<int32_t> order;
-  for (int64_t q = 0; q < nq; q++)
-    if (tasks[q].mode == T_BRUTE_GATHER) order.push_back((int32_t)q);
-  std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-    if (tasks[x].a != tasks[y].a) return tasks[x].a < tasks[y].a;
-    if (tasks[x].b != tasks[y].b) return tasks[x].b < tasks[y].b;
-    return x < y;
-  });
+  {
+    size_t cap = 64;
+    while (cap < (size_t)nq * 2) cap <<= 1;
+    std::vector<int32_t> slot_group(cap, -1), grp_of((size_t)nq, -1), grp_cnt;
+    std::vector<int64_t> slot_a(cap), slot_b(cap);
+    int32_t members = 0;
+    for (int64_t q = 0; q < nq; q++) {
+      if (tasks[q].mode != T_BRUTE_GATHER) continue;
+      const int64_t a = tasks[q].a, b = tasks[q].b;
+      uint64_t h = ((uint64_t)a * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)b * 0xC2B2AE3D27D4EB4Full);
+      size_t pos = (size_t)(h >> 20) & (cap - 1);
+      while (slot_group[pos] >= 0 && (slot_a[pos] != a || slot_b[pos] != b)) pos = (pos + 1) & (cap - 1);
+      if (slot_group[pos] < 0) {
+        slot_group[pos] = (int32_t)grp_cnt.size();
+        slot_a[pos] = a;
+        slot_b[pos] = b;
+        grp_cnt.push_back(0);
+      }
+      grp_of[(size_t)q] = slot_group[pos];
+      grp_cnt[(size_t)slot_group[pos]]++;
+      members++;
+    }
+    std::vector<int32_t> start(grp_cnt.size() + 1, 0);
+    for (size_t g = 0; g < grp_cnt.size(); g++) start[g + 1] = start[g] + grp_cnt[g];
+    order.resize((size_t)members);
+    for (int64_t q = 0; q < nq; q++)
+      if (grp_of[(size_t)q] >= 0) order[(size_t)start[(size_t)grp_of[(size_t)q]]++] = (int32_t)q;
+  }
   std::vector<GemmGroup> groups;
   std::vector<GemmTile> tiles;
   std::vector<int32_t> gq, tq_group, tq_local, rest;

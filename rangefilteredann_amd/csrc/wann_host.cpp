@@ -1074,7 +1074,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     I.view.rs = rs;
     I.view.maxdeg = (int32_t)maxdeg;
     I.view.metric = metric;
-    RoundCfg rc = config_for(I, beam, beam, nq);
+    RoundCfg rc = config_for(I, beam, beam, nq, getenv("WANN_RAW_BIG_LDS") != nullptr);  // (dev: the large-LDS one-wave configuration)
     DevBuf<int32_t> g_table;
     DevBuf<unsigned long long> g_beam;
     SearchArgs sa{};

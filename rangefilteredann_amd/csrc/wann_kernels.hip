@@ -403,6 +403,30 @@ __device__ __forceinline__ int64_t first_ge(const float *fv, int64_t n, float v)
   return e;
 }
 
+// the two lower bounds of a window with their probes issued together: two independent chains of ~log2(n)
+// dependent loads cost the latency of one
+__device__ __forceinline__ void first_ge2(const float *fv, int64_t n, float v1, float v2, uint64_t &r1, uint64_t &r2) {
+  const float f0 = fv[0];
+  int64_t s1 = 0, e1 = n, s2 = 0, e2 = n;
+  if (f0 >= v1) e1 = 0;  // (tree_utils.h:20-22: index 0 is special-cased)
+  if (f0 >= v2) e2 = 0;
+  while (s1 + 1 < e1 || s2 + 1 < e2) {
+    const bool g1 = s1 + 1 < e1, g2 = s2 + 1 < e2;
+    const int64_t m1 = (s1 + e1) / 2, m2 = (s2 + e2) / 2;
+    const float x1 = g1 ? fv[m1] : 0.f, x2 = g2 ? fv[m2] : 0.f;
+    if (g1) {
+      if (x1 >= v1) e1 = m1;
+      else s1 = m1;
+    }
+    if (g2) {
+      if (x2 >= v2) e2 = m2;
+      else s2 = m2;
+    }
+  }
+  r1 = (uint64_t)e1;
+  r2 = (uint64_t)e2;
+}
+
 // prefiltering.h:159-184 (r = n-1: the last point can never be selected)
 __device__ __forceinline__ int64_t prefilter_bound(const float *fv, int64_t n, float v) {
   int64_t l = 0, r = n - 1;
@@ -593,8 +617,8 @@ __device__ __forceinline__ void emit_tree(Emitter &E, float lo0, float hi0, int 
     int mode = it == 0 ? mode0 : W_OPTIMIZED;
     bool mult_one = false;
     if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) continue;  // check_empty (:191-203)
-    const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
-    const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
+    uint64_t istart, eend;
+    first_ge2(ix.labels, ix.n, lo, hi, istart, eend);
     const uint64_t w = eend - istart;
     Centre c;
     bool have_centre = false;
@@ -692,8 +716,8 @@ __device__ __forceinline__ void emit_tree(Emitter &E, float lo0, float hi0, int 
 __device__ __forceinline__ void emit_super(Emitter &E, float lo, float hi) {
   const IndexView &ix = E.A.ix;
   if (hi < ix.labels[0] || lo > ix.labels[ix.n - 1]) return;
-  const uint64_t istart = (uint64_t)first_ge(ix.labels, ix.n, lo);
-  const uint64_t eend = (uint64_t)first_ge(ix.labels, ix.n, hi);
+  uint64_t istart, eend;
+  first_ge2(ix.labels, ix.n, lo, hi, istart, eend);
   const uint64_t w = eend - istart;
   int level;
   int64_t idx = 0;

@@ -45,7 +45,7 @@ struct IndexView {
 };
 
 enum { T_EMPTY = 0, T_GRAPH = 1, T_BRUTE = 2, T_BRUTE_GATHER = 3, T_PARENT = 4 };
-// Task::flags: 1 = heavy (schedule first), 2 = final_beam_multiply forced to 1, 4 = speculative sub-task
+// Task::flags: 1 = heavy (schedule first), 2 = final_beam_multiply forced to 1, 4 = speculative sub-task, 8 = mid priority
 // (a = beam level, b = parent task index); a T_PARENT task has a = number of sub-tasks, b = first sub-task slot
 enum { M_OPTIMIZED = 0, M_THREE_SPLIT = 1, M_FENWICK = 2 };
 
@@ -82,6 +82,7 @@ struct RouteArgs {
   int32_t *qtask_cnt;  // [nq]
   int32_t *graph_list, *graph_count;
   int32_t *heavy_list, *heavy_count;  // graph tasks expected to need several doublings
+  int32_t *mid_list, *mid_count;      // graph tasks whose first beam may well fail (expected in-window entries < 4k): served second
   int32_t heavy_ratio;                // partition size / window size at or above which a task is heavy
   int32_t *brute_list, *brute_count;
   // speculative doubling: a heavy task spawns one sub-task per beam level b0 << r, r = 0 .. nsub-1,
@@ -108,6 +109,8 @@ struct SearchArgs {
   const int32_t *list_count;
   const int32_t *heavy_list;   // served before `list` (may be null)
   const int32_t *heavy_count;
+  const int32_t *mid_list;     // served between the two (may be null): a late doubling would be the tail of the launch
+  const int32_t *mid_count;
   int32_t *cursor;
   int32_t B;             // first beam of every task of this launch
   int32_t k;

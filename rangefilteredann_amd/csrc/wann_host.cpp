@@ -61,12 +61,12 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
   DevBuf<Task> tasks;
-  DevBuf<int32_t> list_a, list_b, list_final, list_heavy, list_big, list_brute, ints, out_cnt, g_table, g_table_big, qtask_cnt, next_beam;
+  DevBuf<int32_t> list_a, list_b, list_final, list_heavy, list_mid, list_big, list_brute, ints, out_cnt, g_table, g_table_big, qtask_cnt, next_beam;
   DevBuf<unsigned long long> out_key, g_beam;
   DevBuf<long long> sub_hops, sub_cmps;
   DevBuf<int32_t> par_done;
@@ -97,6 +97,7 @@ struct Workspace {
     list_b.ensure(nt);
     list_final.ensure(nt);
     list_heavy.ensure(nt);
+    list_mid.ensure(nt);
     list_big.ensure(3 * nt);
     next_beam.ensure(nt);
     big_stride = (int32_t)nt;
@@ -473,6 +474,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.graph_count = W.ints.p + I_GRAPH_COUNT;
   ra.heavy_list = W.list_heavy.p;
   ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
+  ra.mid_list = W.list_mid.p;
+  ra.mid_count = W.ints.p + I_MID_COUNT;
   ra.heavy_ratio = getenv("WANN_HEAVY_RATIO") ? atoi(getenv("WANN_HEAVY_RATIO")) : 8;
   ra.brute_list = W.list_brute.p;
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
@@ -531,7 +534,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   int64_t graph_n = 0, big_n = 0;
   if (sized) {
     HIP_CHECK(hipEventSynchronize(W.ev_route));
-    graph_n = (int64_t)W.h_ints[I_GRAPH_COUNT] + W.h_ints[I_HEAVY_COUNT];
+    graph_n = (int64_t)W.h_ints[I_GRAPH_COUNT] + W.h_ints[I_HEAVY_COUNT] + W.h_ints[I_MID_COUNT];
     big_n = (int64_t)W.h_ints[I_BIG_COUNT] + W.h_ints[I_BIG_COUNT + 1];
   }
   if (sized && graph_n + big_n > 0) {
@@ -640,6 +643,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.list_count = W.ints.p + I_GRAPH_COUNT;
     sa.heavy_list = W.list_heavy.p;
     sa.heavy_count = W.ints.p + I_HEAVY_COUNT;
+    sa.mid_list = W.list_mid.p;
+    sa.mid_count = W.ints.p + I_MID_COUNT;
     sa.cursor = W.ints.p + I_CURSOR0;
     sa.next_list = W.list_b.p;
     sa.next_count = W.ints.p + I_NEXT0;
@@ -657,6 +662,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       sb.list_count = W.ints.p + I_NEXT0;
       sb.heavy_list = nullptr;
       sb.heavy_count = nullptr;
+      sb.mid_list = nullptr;
+      sb.mid_count = nullptr;
       sb.cursor = W.ints.p + I_CURSOR0 + 1;
       sb.next_list = W.list_a.p;  // cannot be used: cap = max_beam
       sb.next_count = W.ints.p + I_NEXT0 + 1;
@@ -686,6 +693,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         sf.list_count = W.ints.p + I_FINAL0 + 2 + g;
         sf.heavy_list = nullptr;
         sf.heavy_count = nullptr;
+        sf.mid_list = nullptr;
+        sf.mid_count = nullptr;
         sf.cursor = W.ints.p + I_CURSOR0 + 2 + g;
         sf.is_final = 1;
         sf.start_beam = W.next_beam.p;

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
   u64 *gbeam = A.g_beam ? A.g_beam + (size_t)slot * A.g_beam_cap : nullptr;
   int32_t *const gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
   const int heavy = A.heavy_count ? *A.heavy_count : 0;
-  const int total = heavy + *A.list_count;  // ordinary tickets
+  const int mid_end = heavy + (A.mid_count ? *A.mid_count : 0);
+  const int total = mid_end + *A.list_count;  // ordinary tickets
   const int pool_bytes = A.pool_bytes, cap = A.cap_inkernel;
   // BIG: the first npollers workgroups only serve continuations, so that one starts as soon as it is handed over
   bool polling = BIG && (int)blockIdx.x < A.npollers;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
     } else {
       const int t = wave_ticket(A.cursor);
       if (t >= total) break;
-      ti = (t < heavy) ? A.heavy_list[t] : A.list[t - heavy];  // long searches start first
+      ti = (t < heavy) ? A.heavy_list[t] : (t < mid_end) ? A.mid_list[t - heavy] : A.list[t - mid_end];  // long searches start first
     }
     Task task = A.tasks[ti];
     const PartDesc part = ix.parts[task.part];
@@ -455,6 +456,7 @@ struct Emitter {
     A.tasks[ti] = t;
     if (t.mode == T_GRAPH) {
       if (t.flags & 1) A.heavy_list[atomicAdd(A.heavy_count, 1)] = ti;
+      else if (t.flags & 8) A.mid_list[atomicAdd(A.mid_count, 1)] = ti;
       else A.graph_list[atomicAdd(A.graph_count, 1)] = ti;
     } else {
       A.brute_list[atomicAdd(A.brute_count, 1)] = ti;
@@ -479,6 +481,9 @@ struct Emitter {
       // strictly sequential searches.  Such a task is started first and its doubling levels are searched
       // CONCURRENTLY by different waves (each level restarts from scratch anyway, postfilter_vamana.h:
       // 161-172); the sequential rule "first level with >= k in-window results" is applied afterwards.
+      // a first beam that expects fewer than 4k in-window entries fails now and then: such a task starts before the
+      // bulk, so that its second, longer search is not what the launch ends with
+      if (t.mode == T_GRAPH && (uint64_t)A.beam * w < 4ull * (uint64_t)A.k * (uint64_t)pd.n) t.flags |= 8;
       if (t.mode == T_GRAPH && w > 0 && (uint64_t)pd.n / w >= (uint64_t)A.heavy_ratio) {
         t.flags |= 1;
         if (A.spec && n < A.maxt) {

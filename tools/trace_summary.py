@@ -10,3 +10,10 @@ o = np.argsort(-en)[:12]
 print("latest finishers:")
 for i in o:
     print(f"   task {a[i,0]} sub {a[i,1]} big {a[i,2]} beam {a[i,3]} start {st[i]:.2f} end {en[i]:.2f}")
+# occupancy over time: searches in flight per 0.1 ms
+import collections
+bins = collections.Counter()
+for s_, e_ in zip(st, en):
+    for b in range(int(s_ * 10), int(e_ * 10) + 1):
+        bins[b] += 1
+print("in-flight searches per 0.1 ms:", " ".join(str(bins[b]) for b in range(0, int(en.max() * 10) + 1)))

@@ -4,13 +4,21 @@ recall@10 >= 0.95 (BASELINE.json metric), on BASELINE.json configs[1]: SIFT-1M-l
 d = 128, squared L2), 2-ary window search tree (cutoff 1000, R = 64, L = 500, alpha = 1),
 query method "optimized_postfilter", 10 000 queries per GPU, k = 10.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-A "step" is one batch_search over the rank's 10 000-query batch (queries, windows and outputs
-resident in HBM) at the fastest sweep setting whose recall@10 exceeds 0.95 at window fraction
-2^-3 (experiments/create_table.py:23-28: QPS@recall = max qps over settings with recall > tau).
-Multi-GPU is weak scaling: the index is replicated, every rank searches its own 10 000 queries
-and the per-rank top-k are all-gathered over RCCL inside the timed region.
+N > 1: one process per GPU.  Either the caller starts the ranks (python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or --
+when WORLD_SIZE is unset -- this script starts them itself as a torch.distributed.run CHILD process
+before anything here has touched the GPU and relays the child's JSON line.
+
+A "step" is one sharded batch_search (rangefilteredann_amd.distributed.sharded_batch_search) over
+the job's query batch -- queries, windows and outputs resident in HBM -- at the fastest sweep
+setting whose recall@10 exceeds 0.95 at window fraction 2^-3 (experiments/create_table.py:23-28:
+QPS@recall = max qps over settings with recall > tau).  The index is replicated on every GPU, the
+batch is cut into contiguous per-rank shards that keep their global query numbers, and the per-shard
+top-k are exchanged with ONE RCCL all-gather inside the timed region.
+  --scaling weak   (default) 10 000 queries PER GPU: the job's batch is N x 10 000 queries
+  --scaling strong ONE 10 000-query batch cut N ways (1 250 queries per GPU at N = 8)
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      algorithmic bytes of the beam-search kernel / its HIP-event time vs 8 TB/s HBM
@@ -55,13 +63,13 @@ def quiet_stdout():
         os.close(dn)
 
 
-def make_data(n, d, nq, rank):
+def make_data(n, d, nq, draws=1):
+    """Points, `draws` consecutive query batches of nq rows (concatenated) and labels: the same on every rank."""
     import numpy as np
     from util import sift_like
     g = sift_like(n, d, 1234)
     X = g(n)
-    for _ in range(rank + 1):  # rank r gets the (r+1)-th draw of the same law: distinct query batches
-        Q = g(nq)
+    Q = np.concatenate([g(nq) for _ in range(max(1, draws))])
     rng = np.random.default_rng(4321)
     labels = ((rng.permutation(n) + 0.5) / n).astype(np.float32)
     return X, Q, labels
@@ -110,11 +118,53 @@ def recall_of(torch, gt, gcnt, ids):
     return float((hit[valid].double() / gcnt[valid].double()).mean().item())
 
 
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launcher_cmd(n_ranks, argv, port):
+    """The command this script runs as a child for --gpus N > 1 (the driver's own launch line)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n_ranks, argv):
+    """Start the ranks as a CHILD process (this process has not imported torch or made a HIP call, and never
+    replaces itself: exec from a GPU-initialised process is forbidden on the pool) and relay its output."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    proc = subprocess.run(launcher_cmd(n_ranks, argv, free_port()), env=env)
+    return proc.returncode
+
+
+def launch_check():
+    """Self-test of the launch path without a GPU (tests/test_bench_launch.py): rendezvous on gloo, one all-gather of
+    the rank numbers, rank 0 prints a JSON line."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+    if rank == 0:
+        print(json.dumps({"launch_check": world, "ranks": [int(t.item()) for t in got]}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --nq queries per GPU; strong: ONE --nq-query batch cut across the GPUs")
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=128)
@@ -123,11 +173,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    # ---- N > 1 without a launcher: start the ranks ourselves, BEFORE torch / HIP are touched in this process
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_check:
+        return launch_check()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     ncpu = os.cpu_count() or 1
     os.environ.setdefault("PARLAY_NUM_THREADS", str(max(1, ncpu // world)))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -138,19 +196,24 @@ def main():
     import torch.distributed as dist
     import rangefilteredann_amd  # noqa: F401  (fails loudly when the HIP extension is missing)
     import window_ann as wa
-    from rangefilteredann_amd.distributed import sharded_batch_search  # noqa: F401
+    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search
 
     assert torch.cuda.is_available() and wa.device_count() > local_rank, "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = "WORLD_SIZE" in os.environ  # started by a launcher (also at N = 1): the RCCL path runs
+    if distributed:
         dist.init_process_group("nccl", device_id=dev)
 
-    n, d, nq = args.n, args.dim, args.nq
+    n, d = args.n, args.dim
+    draws = world if args.scaling == "weak" else 1
+    gnq = args.nq * draws                      # the job's batch
+    lo, hi = shard_bounds(gnq, world, rank)    # this rank's shard (global query numbers)
+    nq = hi - lo
     R, L, alpha, cutoff, split = 64, 500, 1.0, 1000, 2
     t0 = time.time()
-    X, Q, labels = make_data(n, d, nq, rank)
-    log(f"data n={n} d={d} nq={nq} in {time.time() - t0:.1f}s; host cpus={ncpu}")
+    X, Qg, labels = make_data(n, d, args.nq, draws)
+    log(f"data n={n} d={d} batch={gnq} ({args.scaling} scaling, {world} rank(s)) in {time.time() - t0:.1f}s; host cpus={ncpu}")
 
     cache = os.path.join(args.cache, f"siftlike_n{n}_d{d}_R{R}_L{L}_c{cutoff}_s{split}") + "/"
     os.makedirs(cache, exist_ok=True)
@@ -165,7 +228,8 @@ def main():
     Xt = torch.from_numpy(X).to(dev)
     x2 = (Xt * Xt).sum(1)
     labt = torch.from_numpy(labels).to(dev)
-    Qt = torch.from_numpy(Q).to(dev)
+    Qgt = torch.from_numpy(Qg).to(dev)         # the whole batch on every rank (sharded_batch_search's contract)
+    Q, Qt = Qg[lo:hi], Qgt[lo:hi]
     ls = np.sort(labels)
     ids_t = torch.empty((nq, K), dtype=torch.int32, device=dev)
     dist_t = torch.empty((nq, K), dtype=torch.float32, device=dev)
@@ -173,13 +237,19 @@ def main():
     def qparams(mod, beam, mult):
         return mod.QueryParams(K, beam, 1.35, 10_000_000, 10_000, mult, 10000, None, False)
 
+    def global_windows(p, seed):
+        """windows of the whole batch: draw r uses seed + r (a weak-scaling rank's shard is one draw)"""
+        return np.concatenate([make_windows(ls, args.nq, p, seed + r) for r in range(draws)])
+
     def run(Wt, beam, mult):
-        index.batch_search_device(Qt.data_ptr(), Wt.data_ptr(), nq, 0, "optimized_postfilter", qparams(wa, beam, mult),
+        """this rank's shard through the device-pointer C-ABI entry point"""
+        index.batch_search_device(Qt.data_ptr(), Wt.data_ptr(), nq, lo, "optimized_postfilter", qparams(wa, beam, mult),
                                   ids_t.data_ptr(), dist_t.data_ptr(), 0)
 
     def sweep(p, seed):
-        W = make_windows(ls, nq, p, seed)
-        Wt = torch.from_numpy(W).to(dev)
+        Wg = global_windows(p, seed)
+        Wgt = torch.from_numpy(Wg).to(dev)
+        Wt = Wgt[lo:hi]
         gt, gcnt = ground_truth(torch, Xt, x2, labt, Qt, Wt, K)
         rows = []
         for beam, mult in SWEEP:
@@ -190,68 +260,83 @@ def main():
             c = index.counters()
             rec = recall_of(torch, gt, gcnt, ids_t)
             rows.append(dict(beam=beam, mult=mult, recall=rec, wall_ms=wall * 1e3, device_ms=c["device_ms"]))
-            if rec > 0.9995 and mult == 1:
-                pass
         ok = [r for r in rows if r["recall"] > 0.95]
         best = min(ok, key=lambda r: r["wall_ms"]) if ok else None
-        return W, Wt, rows, best
+        return Wg, Wgt, rows, best
 
     # ---- headline fraction: pick the setting, then time K steps
     if args.setting:
         sb, sm = (int(x) for x in args.setting.split(","))
-        W = make_windows(ls, nq, args.fraction, 1000 + rank)
-        Wt = torch.from_numpy(W).to(dev)
+        Wg = global_windows(args.fraction, 1000)
+        Wgt = torch.from_numpy(Wg).to(dev)
         rows, best = [], dict(beam=sb, mult=sm, recall=float("nan"), wall_ms=0.0, device_ms=0.0)
     else:
-        W, Wt, rows, best = sweep(args.fraction, 1000 + rank)
+        Wg, Wgt, rows, best = sweep(args.fraction, 1000)
+    W, Wt = Wg[lo:hi], Wgt[lo:hi]
     for r in rows:
         log(f"  2^{args.fraction}: beam {r['beam']:4d} x{r['mult']}  recall {r['recall']:.4f}  {r['wall_ms']:.2f} ms  -> {nq / r['wall_ms'] * 1e3:,.0f} QPS")
     if best is None:
         best = max(rows, key=lambda r: r["recall"])
         log("WARNING: no sweep setting reached recall 0.95; timing the most accurate one")
     beam, mult = best["beam"], best["mult"]
-    if world > 1:  # every rank must time the same setting: take rank 0's choice
+    if distributed:  # every rank must time the same setting: take rank 0's choice
         bm = torch.tensor([beam, mult], device=dev)
         dist.broadcast(bm, 0)
         beam, mult = int(bm[0]), int(bm[1])
 
-    gather_buf = torch.empty((world * nq, K, 2), dtype=torch.int32, device=dev) if world > 1 else None
-    send_buf = torch.empty((nq, K, 2), dtype=torch.int32, device=dev) if world > 1 else None
-
-    def step():
-        run(Wt, beam, mult)
-        if world > 1:  # exchange the per-rank top-k (ids, dists) over RCCL/xGMI
-            send_buf[:, :, 0] = ids_t
-            send_buf[:, :, 1] = dist_t.view(torch.int32)
-            dist.all_gather_into_tensor(gather_buf, send_buf)
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     agg = dict(beam_searches=0, hops=0, dist_cmps=0, label_reads=0, brute_rows=0, search_kernel_ms=0.0, device_ms=0.0, rounds=0)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    qp_run = qparams(wa, beam, mult)
+
+    def search_fn(q, r, base):
+        """local search of one shard: (nq_shard, d) / (nq_shard, 2) device tensors, global number of its first query"""
+        m = q.shape[0]
+        index.batch_search_device(q.data_ptr(), r.data_ptr(), m, base, "optimized_postfilter", qp_run,
+                                  ids_t.data_ptr(), dist_t.data_ptr(), 0)
         c = index.counters()
         for kk in agg:
             agg[kk] += c[kk]
+        return ids_t[:m], dist_t[:m]
+
+    def step():
+        # query shards -> HIP batch_search on this rank's GPU -> ONE all-gather of the per-shard top-k over RCCL/xGMI
+        return sharded_batch_search(search_fn, Qgt, Wgt, K)
+
+    for _ in range(args.warmup):
+        step()
+    if distributed:
+        dist.barrier()
     torch.cuda.synchronize()
-    if world > 1:
+    for kk in agg:
+        agg[kk] = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        all_ids, all_d = step()
+    torch.cuda.synchronize()
+    if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     ms_per_step = elapsed / args.steps * 1e3
-    qps = world * nq * args.steps / elapsed
-    final_recall = recall_of(torch, *ground_truth(torch, Xt, x2, labt, Qt, Wt, K), ids_t)
+    qps = gnq * args.steps / elapsed
+    # recall of the gathered result rows of this rank's shard (every rank holds every row), averaged over the ranks
+    gt_l, gcnt_l = ground_truth(torch, Xt, x2, labt, Qt, Wt, K)
+    final_recall = recall_of(torch, gt_l, gcnt_l, all_ids[lo:hi])
+    if distributed:
+        fr = torch.tensor([final_recall * nq, float(nq)], dtype=torch.float64, device=dev)
+        dist.all_reduce(fr)
+        final_recall = float(fr[0] / fr[1])
+        sums = torch.tensor([float(agg[kk]) for kk in ("beam_searches", "hops", "dist_cmps", "label_reads", "rounds")] +
+                            [agg["search_kernel_ms"], agg["device_ms"]], dtype=torch.float64, device=dev)
+        mx = sums[5:].clone()
+        dist.all_reduce(sums)                         # work counters: summed over the ranks
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)     # kernel time: the slowest rank's
     # the reference's own boundary (numpy in, numpy out): the same batch through the host-buffer entry point,
     # PCIe copies included -- reported beside `value`, never as `value`
     host_ms = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         Wn = W.astype(np.float32)
         index.batch_search(Q, Wn, nq, "optimized_postfilter", qparams(wa, beam, mult))
         t1 = time.perf_counter()
@@ -259,39 +344,41 @@ def main():
             index.batch_search(Q, Wn, nq, "optimized_postfilter", qparams(wa, beam, mult))
         host_ms = (time.perf_counter() - t1) / 5 * 1e3
 
-    # B = 4(R+1)*hops + d*sizeof(T)*dist_cmps + 4*|beam_out|  per search
-    alg_bytes = 4 * (R + 1) * agg["hops"] + d * 4 * agg["dist_cmps"] + 4 * agg["label_reads"]
-    kern_s = agg["search_kernel_ms"] / 1e3
+    # B = 4(R+1)*hops + d*sizeof(T)*dist_cmps + 4*|beam_out|  per search.  N > 1: bytes of ALL ranks over
+    # the slowest rank's kernel time = the job's aggregate rate, against N x the per-GPU peak.
+    if distributed:
+        hops_all, cmps_all, labs_all = float(sums[1]), float(sums[2]), float(sums[3])
+        searches_all, rounds_all = float(sums[0]), float(sums[4]) / world
+        kern_ms, dev_ms = float(mx[0]), float(mx[1])
+    else:
+        hops_all, cmps_all, labs_all = agg["hops"], agg["dist_cmps"], agg["label_reads"]
+        searches_all, rounds_all = agg["beam_searches"], agg["rounds"]
+        kern_ms, dev_ms = agg["search_kernel_ms"], agg["device_ms"]
+    alg_bytes = 4 * (R + 1) * hops_all + d * 4 * cmps_all + 4 * labs_all
+    kern_s = kern_ms / 1e3
     achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
-    traffic = None
-    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            pj = json.load(open(pmc_path))
-            if pj.get("beam") == beam and pj.get("mult") == mult and pj.get("n") == n:
-                traffic = pj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = dict(bound="hbm", kernel="k_search", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+    traffic, traffic_source = measured_traffic(beam, mult, n, gnq // world)
+    roofline = dict(bound="hbm", kernel="k_search", achieved=round(achieved, 1), peak=HBM_PEAK_GBS * world, unit="GB/s",
+                    frac=round(achieved / (HBM_PEAK_GBS * world), 4), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_step=int(alg_bytes / args.steps),
-                    launches_per_step=agg["rounds"] / args.steps,
-                    kernel_ms_per_step=round(agg["search_kernel_ms"] / args.steps, 4),
-                    device_ms_per_step=round(agg["device_ms"] / args.steps, 4),
-                    searches_per_step=agg["beam_searches"] / args.steps, hops_per_step=agg["hops"] / args.steps,
-                    dist_cmps_per_step=agg["dist_cmps"] / args.steps)
+                    launches_per_step=rounds_all / args.steps,
+                    kernel_ms_per_step=round(kern_ms / args.steps, 4),
+                    device_ms_per_step=round(dev_ms / args.steps, 4),
+                    searches_per_step=searches_all / args.steps, hops_per_step=hops_all / args.steps,
+                    dist_cmps_per_step=cmps_all / args.steps)
 
     result = {
         "metric": "QPS @ recall@10>=0.95, window fraction 2^%d" % args.fraction, "value": round(qps, 1), "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"SIFT-1M-like n={n} d={d} L2, 2-WST (cutoff {cutoff}, R={R}, L={L}, alpha={alpha}) optimized_postfilter, "
-                               f"window 2^{args.fraction}, {nq} queries/GPU, k={K}",
+                               f"window 2^{args.fraction}, {gnq} queries per step ({nq} on rank 0), k={K}",
                    "beam": beam, "final_beam_multiply": mult, "recall_at_10": round(final_recall, 4),
                    "build_s": round(build_s, 1), "index_gib": round(index.device_bytes() / 2**30, 2),
                    "host_buffer_call_ms": None if host_ms is None else round(host_ms, 3),
                    "host_buffer_qps": None if host_ms is None else round(nq / host_ms * 1e3, 1),
-                   "parallelism": f"replicated index x{world}, query shards, RCCL all-gather of top-k" if world > 1 else "1 GPU"},
+                   "parallelism": (f"replicated index x{world}, contiguous query shards, one RCCL all-gather of the per-shard top-k per step"
+                                   if distributed else "1 GPU")},
         "roofline": roofline,
     }
 
@@ -299,7 +386,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(np, X, Q, labels, W, nq, beam, mult, cache, (R, L, alpha, cutoff, split),
-                                                  ids_t.cpu().numpy().view(np.uint32), dist_t.cpu().numpy(), qparams)
+                                                  all_ids.cpu().numpy().view(np.uint32), all_d.cpu().numpy(), qparams)
         except Exception as e:  # never lose the GPU number to a baseline problem
             log("cpu baseline failed:", repr(e))
             result["cpu_baseline"] = None
@@ -318,8 +405,25 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
+
+
+def measured_traffic(beam, mult, n, nq_per_gpu):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc cannot run inside this
+    process); returned only when that pass measured this very configuration, with its source named."""
+    best = None
+    prof = os.path.join(REPO, "profiles")
+    for name in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        if not (name.endswith("_pmc_traffic.json")):
+            continue
+        try:
+            pj = json.load(open(os.path.join(prof, name)))
+        except Exception:
+            continue
+        if pj.get("beam") == beam and pj.get("mult") == mult and pj.get("n") == n and pj.get("nq", 10_000) == nq_per_gpu:
+            best = (pj.get("hbm_bytes_per_launch"), f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE pass of this configuration, not this run)")
+    return best if best else (None, None)
 
 
 def cpu_baseline(np, X, Q, labels, W, nq, beam, mult, cache, params, gpu_ids, gpu_dists, qparams):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WANN_ABI_VERSION 1
+#define WANN_ABI_VERSION 2
 
 enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP = 3, WANN_ERR_IO = 4,
        WANN_ERR_UNSUPPORTED = 5 };
@@ -85,6 +85,8 @@ typedef struct {
   int64_t gemm_queries;  /* PrefilterIndex queries scored through the MFMA GEMM path        */
   double device_ms;      /* HIP-event time of the whole call on its stream              */
   double search_kernel_ms; /* HIP-event time summed over beam-search kernel launches    */
+  int64_t recovered_continuations; /* searches a follow-up launch ran because the companion launch's pollers did not
+                                      serve them (launches serialised by the runtime / a profiler); 0 normally     */
 } wann_counters;
 
 typedef struct wann_index wann_index;
@@ -133,8 +135,11 @@ int64_t wann_dim(const wann_index *index);
 int64_t wann_num_levels(const wann_index *index);
 int64_t wann_level_size(const wann_index *index, int64_t level);
 int wann_partition_range(const wann_index *index, int64_t level, int64_t idx, int64_t *start, int64_t *end);
-/* copy partition graph out in the reference's in-memory layout: n x (R+1) int32, slot 0 = degree */
-int wann_partition_graph(const wann_index *index, int64_t level, int64_t idx, int32_t *rows, int64_t cap_rows);
+/* copy partition graph out in the reference's in-memory layout: n x (R+1) int32, slot 0 = degree.  `rows` holds
+ * cap_rows x (max_degree+1) ints; max_degree must equal the index's R (wann_max_degree), cap_rows >= partition size. */
+int wann_partition_graph(const wann_index *index, int64_t level, int64_t idx, int32_t *rows, int64_t cap_rows,
+                         int64_t max_degree);
+int64_t wann_max_degree(const wann_index *index);
 int64_t wann_device_bytes(const wann_index *index);
 
 /* Graph-cache tool: build (host, multi-threaded) and save only the cache files of the

@@ -65,7 +65,7 @@ struct Counters {
   // searches run speculatively at beams beyond the one the sequential loop stops at (extra work,
   // not part of the reference's operation count)
   unsigned long long spec_searches, spec_hops, spec_dist_cmps;
-  unsigned long long poll_timeouts;  // a poller gave up waiting (never expected: the host turns it into an error)
+  unsigned long long poll_timeouts;  // pollers that gave up waiting (serialised launches); the host re-queues what they left unserved
 };
 
 struct RouteArgs {
@@ -158,7 +158,8 @@ struct SearchArgs {
   // static big list waits for such items until every ordinary ticket is done -- instead of to a follow-up launch.
   int32_t npollers;
   int32_t yield_for_big;  // ordinary launch: workgroups [0, #big items) exit at once (room for the companion launch)
-  int32_t *dyn_list;    // [tasks], preset to -1
+  int32_t *dyn_list;    // [tasks], preset to -1; a poller that takes item t leaves -2 - t (the host re-queues entries >= 0)
+  int32_t force_poll_timeout;  // test hook: pollers give up at once (exercises the host's recovery of unserved continuations)
   int32_t *dyn_count, *dyn_cursor;
   int32_t *done_count;  // ordinary tickets completed
 };

@@ -531,7 +531,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
 
   int rounds = 0, nev = 2;
   std::vector<std::pair<int, int>> timed;  // event index pairs around search launches
-  int64_t graph_n = 0, big_n = 0;
+  int64_t graph_n = 0, big_n = 0, recovered = 0;
   if (sized) {
     HIP_CHECK(hipEventSynchronize(W.ev_route));
     graph_n = (int64_t)W.h_ints[I_GRAPH_COUNT] + W.h_ints[I_HEAVY_COUNT] + W.h_ints[I_MID_COUNT];
@@ -566,6 +566,15 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       HIP_CHECK(hipMemsetAsync(d_trace.p, 0, 8, st));
       sa.trace = d_trace.p;
     }
+    // Continuation pollers need the two launches resident together; with launches known to be serialised they are
+    // not used at all (continuations then go to the follow-up launch directly).
+    auto env_on = [](const char *name) {
+      const char *v = getenv(name);
+      return v && *v && strcmp(v, "0") != 0;
+    };
+    const bool use_pollers = !getenv("WANN_NO_POLLERS") &&
+                             (getenv("WANN_FORCE_POLLERS") /* test hook */ ||
+                              (!env_on("HIP_LAUNCH_BLOCKING") && !env_on("AMD_SERIALIZE_KERNEL") && !env_on("CUDA_LAUNCH_BLOCKING")));
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0) {
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds);
       a.B = (int32_t)first_beam;
@@ -601,8 +610,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         big.g_table = W.g_table_big.p;
         a.yield_for_big = getenv("WANN_NO_YIELD") ? 0 : 1;
         a.big_count = W.ints.p + I_BIG_COUNT;
-        if (!getenv("WANN_NO_POLLERS")) {
+        if (use_pollers) {
           a.npollers = big.npollers = 16;
+          big.force_poll_timeout = getenv("WANN_FORCE_POLL_TIMEOUT") ? 1 : 0;  // test hook
           a.big_cap = with_big_cap;
           a.big_count = W.ints.p + I_BIG_COUNT;
           a.dyn_list = big.dyn_list = W.list_big.p + 2 * (size_t)W.big_stride;
@@ -653,6 +663,25 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
+    // continuations handed to the companion launch's pollers that nobody served (the runtime serialised the two
+    // launches, or a poller gave up): entries >= 0 of dyn_list.  They join the follow-up launch (next_beam holds
+    // the beam each one continues with), so the batch completes with the same rows.
+    if (big_n > 0 && use_pollers && W.h_ints[I_DYN_COUNT] > 0) {
+      const int dyn_n = W.h_ints[I_DYN_COUNT];
+      std::vector<int32_t> dl((size_t)dyn_n), unserved;
+      HIP_CHECK(hipMemcpyAsync(dl.data(), W.list_big.p + 2 * (size_t)W.big_stride, (size_t)dyn_n * 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      for (int32_t t : dl)
+        if (t >= 0) unserved.push_back(t);
+      if (!unserved.empty()) {
+        HIP_CHECK(hipMemcpyAsync(W.list_b.p + next_n, unserved.data(), unserved.size() * 4, hipMemcpyHostToDevice, st));
+        next_n += (int)unserved.size();
+        HIP_CHECK(hipMemcpyAsync(W.ints.p + I_NEXT0, &next_n, 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));  // `unserved` / next_n back the uploads
+        recovered = (int64_t)unserved.size();
+        if (getenv("WANN_VERBOSE")) fprintf(stderr, "[wann batch] %d continuations not served by the pollers: re-queued\n", (int)unserved.size());
+      }
+    }
     // launch 2 (rare): the tasks that must double beyond the cap finish their loop in huge mode
     if (next_n > 0) {
       int64_t nb = b0;
@@ -768,8 +797,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.spec_hops = (int64_t)W.h_ctr->spec_hops;
   I.last.spec_dist_cmps = (int64_t)W.h_ctr->spec_dist_cmps;
   I.last.rounds = rounds;
-  if (W.h_ctr->poll_timeouts)
-    throw std::runtime_error("internal error: a continuation poller of the beam-search launch timed out; results may be incomplete");
+  I.last.recovered_continuations = recovered;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");
@@ -871,7 +899,7 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
   // exact in any order, so the fp32 kernels return exactly the reference's (float)int32 distances.
   if (dtype != WANN_DTYPE_F32) {
     const int64_t term = (metric == WANN_METRIC_MIPS && dtype == WANN_DTYPE_I8) ? 128 * 128 : 255 * 255;
-    if (d * term >= ((int64_t)1 << 24)) {
+    if (d * term > ((int64_t)1 << 24)) {  // partial sums up to 2^24 inclusive are exact in fp32
       fail(WANN_ERR_UNSUPPORTED, "uint8/int8 point sets are supported up to 258 dimensions (1024 for int8 inner products): beyond "
                                  "that fp32 accumulation is no longer exact");
       return nullptr;
@@ -984,14 +1012,18 @@ int wann_partition_range(const wann_index *I, int64_t level, int64_t idx, int64_
   *end = P.start + P.n;
   return WANN_OK;
 }
-int wann_partition_graph(const wann_index *I, int64_t level, int64_t idx, int32_t *rows, int64_t cap_rows) {
-  if (!I || level < 0 || level >= (int64_t)I->H.levels.size() || idx < 0 || idx >= (int64_t)I->H.levels[level].size())
+int wann_partition_graph(const wann_index *I, int64_t level, int64_t idx, int32_t *rows, int64_t cap_rows, int64_t max_degree) {
+  if (!I || !rows || level < 0 || level >= (int64_t)I->H.levels.size() || idx < 0 || idx >= (int64_t)I->H.levels[level].size())
     return fail(WANN_ERR_INVALID, "partition out of range");
   const HostPart &P = I->H.levels[level][idx];
   if (P.g.n != P.n || cap_rows < P.n) return fail(WANN_ERR_INVALID, "no graph / buffer too small");
-  memcpy(rows, P.g.rows.data(), P.g.rows.size() * 4);
+  if (max_degree != (int64_t)P.g.maxdeg)
+    return fail(WANN_ERR_INVALID, "max_degree " + std::to_string((long long)max_degree) + " does not match the index's R = " +
+                                      std::to_string((long long)P.g.maxdeg) + " (rows are R+1 ints wide)");
+  memcpy(rows, P.g.rows.data(), (size_t)P.n * (size_t)(P.g.maxdeg + 1) * 4);
   return WANN_OK;
 }
+int64_t wann_max_degree(const wann_index *I) { return I ? I->H.spec.R : -1; }
 int64_t wann_device_bytes(const wann_index *I) { return I ? I->device_bytes : -1; }
 
 int wann_build_cache_shard(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,

@@ -92,23 +92,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
       const int d = wave_ticket(A.dyn_cursor);
       int item = -1;
       bool settled = false;
-      for (int spin = 0; spin < (1 << 22); spin++) {
-        int have = 0, fin = 0;
+      // Bounded wait.  The producers are waves of a DIFFERENT launch; HIP does not promise that the two launches are
+      // resident together (a shared hardware queue, HIP_LAUNCH_BLOCKING / AMD_SERIALIZE_KERNEL, rocprofv3 --pmc all
+      // serialise them).  A poller gives up soon when no ordinary wave has ever taken a ticket (the other launch has
+      // not started: it may be queued BEHIND this one) and after a long bound otherwise; whatever it leaves unserved
+      // stays in dyn_list (entries >= 0) and the host hands it to a follow-up launch (run_batch).
+      const int spins = A.force_poll_timeout ? 0 : (1 << 22);
+      for (int spin = 0; spin < spins; spin++) {
+        int have = 0, fin = 0, idle = 0;
         if (lane == 0) {
           // relaxed device-scope atomics: served by the memory side, no cache invalidation per poll
           fin = __hip_atomic_load(A.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total;
           have = __hip_atomic_load(A.dyn_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > d;
           if (have) item = __hip_atomic_load(A.dyn_list + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (spin >= (1 << 12) && (spin & 255) == 0)
+            idle = total > 0 && __hip_atomic_load(A.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
         }
         item = uni(item);
         if (item >= 0 || (uni(fin) && !uni(have))) {
           settled = true;
           break;
         }
+        if (uni(idle)) break;  // serialised dispatch: nobody will produce while this launch occupies the queue
         __builtin_amdgcn_s_sleep(32);
       }
       if (!settled && lane == 0) atomicAdd(&A.ctr->poll_timeouts, 1ull);
-      if (item < 0) break;  // nothing more can arrive
+      if (item < 0) break;  // nothing more can arrive (or given up)
+      if (lane == 0) __hip_atomic_store(A.dyn_list + d, -2 - item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // served
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer's writes (next_beam) before its publication
       ti = item;
       dyn = true;

@@ -146,6 +146,7 @@ class Index {
     d["spec_hops"] = c.spec_hops;
     d["spec_dist_cmps"] = c.spec_dist_cmps;
     d["gemm_queries"] = c.gemm_queries;
+    d["recovered_continuations"] = c.recovered_continuations;
     d["device_ms"] = c.device_ms;
     d["search_kernel_ms"] = c.search_kernel_ms;
     return d;
@@ -163,7 +164,7 @@ class Index {
   py::array_t<int32_t> partition_graph(int64_t level, int64_t idx, int64_t max_degree) const {
     auto [s, e] = partition_range(level, idx);
     py::array_t<int32_t> rows({(size_t)(e - s), (size_t)(max_degree + 1)});
-    if (wann_partition_graph(h_, level, idx, rows.mutable_data(), e - s)) raise_last("partition_graph");
+    if (wann_partition_graph(h_, level, idx, rows.mutable_data(), e - s, max_degree)) raise_last("partition_graph");
     return rows;
   }
   int64_t device_bytes() const { return wann_device_bytes(h_); }
@@ -290,6 +291,13 @@ PYBIND11_MODULE(_window_ann, m) {
   add_variant<WANN_METRIC_MIPS, WANN_DTYPE_U8>(m, "UInt8Mips");
   add_variant<WANN_METRIC_L2, WANN_DTYPE_I8>(m, "Int8Euclidian");
   add_variant<WANN_METRIC_MIPS, WANN_DTYPE_I8>(m, "Int8Mips");
+
+  // experiments/wrapper.py:245 spells the uint8 classes "Uint8" while the reference registers "UInt8"
+  // (python_bindings.cpp:74-79), so its uint8 constructors raise AttributeError there; both spellings resolve here.
+  for (const char *cls : {"PrefilterIndex", "RangeFilterTreeIndex", "PostfilterVamanaIndex", "VamanaRangeFilterTreeIndex",
+                          "SuperOptimizedPostfilterTreeIndex"})
+    for (const char *metric : {"Euclidian", "Mips"})
+      m.attr((std::string(cls) + "Uint8" + metric).c_str()) = m.attr((std::string(cls) + "UInt8" + metric).c_str());
 
   m.def("device_count", [] { return wann_device_count(); });
   m.def("abi_version", [] { return wann_abi_version(); });

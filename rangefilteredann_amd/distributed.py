@@ -34,12 +34,13 @@ def sharded_batch_search(search_fn: Callable, queries: torch.Tensor, ranges: tor
                          pad_id: int = 0, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Search `queries` (nq, d) / `ranges` (nq, 2) -- identical on every rank -- by shards and return
     the full (nq, k) ids (int32 view of uint32) and dists on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    grouped = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if grouped else 1
+    rank = dist.get_rank(group) if grouped else 0
     nq = queries.shape[0]
     lo, hi = shard_bounds(nq, world, rank)
     ids, dists = search_fn(queries[lo:hi], ranges[lo:hi], lo)
-    if world == 1:
+    if not grouped:  # no process group: one process, one GPU.  (A group of ONE rank still runs the collective.)
         return ids, dists
     cap = shard_capacity(nq, world)
     # all-gather needs equal sizes: pad the short shards (at most one row)

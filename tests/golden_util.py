@@ -67,10 +67,35 @@ def cases(data, kind):
         yield f[4:], method, int(beam), int(mult), p
 
 
-def same_rows(exp_ids, exp_d, got_ids, got_d, tie_aware):
-    """Row-wise equality; tie_aware: distances equal exactly and ids equal as multisets inside each
-    run of equal distances, except a run cut by the k boundary where only membership in the
-    candidate set can be checked."""
+class RowContext:
+    """What a tie-aware comparison needs to VERIFY an id that the expectation does not list: the inputs of the batch.
+    metric: "l2" or "mips"; ids are original point numbers (rows of X)."""
+
+    def __init__(self, X, labels, Q, W, metric):
+        self.X, self.labels, self.Q, self.W, self.metric = X, np.asarray(labels, dtype=np.float32), Q, np.asarray(W), metric
+
+    def plausible(self, row, pid, dist):
+        """pid lies in the row's label window and its (float64) distance to the query is `dist` up to fp32 rounding"""
+        if pid < 0 or pid >= len(self.labels):
+            return False
+        lo, hi = np.float32(self.W[row][0]), np.float32(self.W[row][1])
+        if not (lo <= self.labels[pid] <= hi):
+            return False
+        x, q = self.X[pid].astype(np.float64), self.Q[row].astype(np.float64)
+        d64 = -float(x @ q) if self.metric == "mips" else float(((x - q) ** 2).sum())
+        return abs(d64 - float(dist)) <= 1e-5 * max(1.0, abs(d64))
+
+
+def metric_of(class_suffix):
+    return "mips" if class_suffix.endswith("Mips") else "l2"
+
+
+def same_rows(exp_ids, exp_d, got_ids, got_d, tie_aware, ctx=None):
+    """Row-wise equality; tie_aware: distances equal exactly and ids equal as multisets inside each run of equal
+    distances.  A run cut by the k boundary may be the prefix of a larger tie group of which the expectation shows
+    only a part: there every returned id must be one the expectation lists or -- checked from the batch's inputs
+    (ctx, required) -- a point inside the query's window at exactly that distance, and no id may repeat more often
+    than the expectation repeats ids in that run."""
     if exp_ids.shape != got_ids.shape:
         return False, "shape"
     if not np.array_equal(exp_d, got_d):
@@ -81,6 +106,8 @@ def same_rows(exp_ids, exp_d, got_ids, got_d, tie_aware):
     if not tie_aware:
         bad = np.argwhere(exp_ids != got_ids)[0]
         return False, f"id mismatch at {tuple(bad)}: {exp_ids[bad[0]]} vs {got_ids[bad[0]]}"
+    if ctx is None:
+        raise ValueError("tie-aware comparison needs the batch inputs (RowContext) to verify ids at the k boundary")
     k = exp_ids.shape[1]
     for r in np.unique(np.argwhere(exp_ids != got_ids)[:, 0]):
         j = 0
@@ -88,10 +115,18 @@ def same_rows(exp_ids, exp_d, got_ids, got_d, tie_aware):
             e = j
             while e + 1 < k and exp_d[r, e + 1] == exp_d[r, j]:
                 e += 1
-            if e == k - 1:  # run touches the k boundary: it may be the prefix of a larger tie group
-                pass
-            elif sorted(exp_ids[r, j:e + 1]) != sorted(got_ids[r, j:e + 1]):
-                return False, f"row {r}: ids differ outside a distance tie"
+            exp_run, got_run = sorted(exp_ids[r, j:e + 1].tolist()), sorted(got_ids[r, j:e + 1].tolist())
+            if exp_run != got_run:
+                if e != k - 1:
+                    return False, f"row {r}: ids differ outside a distance tie"
+                # run touches the k boundary: unknown members must be verifiable members of the same tie group
+                listed = set(exp_run)
+                for pid in got_run:
+                    if pid not in listed and not ctx.plausible(int(r), int(pid), exp_d[r, j]):
+                        return False, f"row {r}: id {pid} at the k boundary is not a window point at distance {exp_d[r, j]!r}"
+                max_rep = max(exp_run.count(x) for x in listed)
+                if any(got_run.count(x) > max_rep for x in set(got_run)):
+                    return False, f"row {r}: an id repeats inside the boundary tie group"
             j = e + 1
     return True, ""
 
@@ -110,7 +145,8 @@ def replay(mod, name, kind, tmpdir, max_cases=None):
         ids, dists = idx.batch_search(*args, qp)
         # merged / brute-forced results go through the reference's unstable sort-by-distance
         tie_aware = kind in TIE_AWARE_KINDS or method in ("fenwick", "three_split") or p in ("-7", "edge")
-        ok, why = same_rows(data["ids|" + key], data["dists|" + key], ids, dists, tie_aware)
+        ctx = RowContext(data["X"], data["labels"], Q, W, metric_of(FIXTURES[name]))
+        ok, why = same_rows(data["ids|" + key], data["dists|" + key], ids, dists, tie_aware, ctx)
         if not ok:
             failures.append(f"{name} {key}: {why}")
         n += 1

@@ -23,7 +23,7 @@ def test_header_symbols_exported(wa):
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"libwann.so does not export {n}"
-    assert lib.wann_abi_version() == 1
+    assert lib.wann_abi_version() == 2
 
 
 def test_python_surface_matches_reference_names(wa):
@@ -37,6 +37,28 @@ def test_python_surface_matches_reference_names(wa):
     bp = wa.BuildParams(max_degree=64, limit=500, alpha=1.0, cache_path="index_cache/x/")
     assert qp is not None and bp is not None
     assert wa.defaults.GRAPH_DEGREE == 64
+
+
+def test_harness_resolves_every_class_name(wa):
+    """experiments/wrapper.py:233-268 builds class names from (prefix, metric, dtype); its 'Uint8' spelling must resolve too"""
+    from rangefilteredann_amd import harness
+    for ctor in (harness.prefilter_index_constructor, harness.postfilter_vamana_constructor,
+                 harness.vamana_range_filter_tree_constructor, harness.super_optimized_postfilter_tree_constructor):
+        for metric in ("Euclidian", "mips"):
+            for dtype in ("float", "uint8", "int8"):
+                assert ctor(metric, dtype) is not None
+    assert wa.PrefilterIndexUint8Euclidian is wa.PrefilterIndexUInt8Euclidian
+
+
+def test_int8_inner_products_accept_1024_dimensions(wa):
+    """d * 128 * 128 = 2^24 exactly at d = 1024: every partial sum is still exact in fp32 (wann.h promises 1024)"""
+    lab = np.arange(16, dtype=np.float32)
+    with pytest.raises(RuntimeError) as e:
+        wa.PrefilterIndexInt8Mips(np.zeros((16, 1025), dtype=np.int8), lab)
+    assert "1024" in str(e.value)
+    if wa.device_count() == 0:
+        with pytest.raises(RuntimeError, match="no usable gfx950 device"):
+            wa.PrefilterIndexInt8Mips(np.zeros((16, 1024), dtype=np.int8), lab)
 
 
 def test_no_gpu_means_loud_failure(wa):

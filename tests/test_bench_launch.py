@@ -1,0 +1,39 @@
+"""CPU: `python bench.py --gpus N` with no launcher in the environment starts its N ranks itself (a
+torch.distributed.run child, started before the parent touches torch or HIP) and relays rank 0's JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+from util import REPO
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WANN_NO_TORCH"] = "1"
+    return env
+
+
+def test_launcher_command_is_the_drivers_launch_line():
+    sys.path.insert(0, REPO)
+    import bench
+    cmd = bench.launcher_cmd(4, ["--gpus", "4", "--steps", "2"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+
+
+def test_gpus_2_without_launcher_starts_two_ranks():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launch-check"],
+                         capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"launch_check": 2, "ranks": [0, 1]}
+
+
+def test_gpus_must_match_world_size():
+    env = _clean_env()
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--launch-check"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr

@@ -2,11 +2,13 @@
 the same seeded inputs and against the golden vectors of the real reference.  Integer / index
 results must be bit-exact; float distances are compared bit-exactly too (the kernels reproduce the
 reference's fp32 evaluation order), which is stricter than north_star's 1e-5 relative bound."""
+import os
+
 import numpy as np
 import pytest
 
 import golden_util as gu
-from util import distinct_labels, sift_like, unit_mixture, windows
+from util import REPO, distinct_labels, sift_like, unit_mixture, windows
 
 pytestmark = pytest.mark.gpu
 FLT_MAX = np.finfo(np.float32).max
@@ -76,7 +78,8 @@ def test_golden_reference_outputs(wa, gpu, tmp_path, name, kind):
         args = (Q, data["W_" + p], nq) + ((method,) if kind.endswith("RangeFilterTreeIndex") else ())
         ids, dists = idx.batch_search(*args, _qp(wa, beam, mult, K))
         tie = kind in gu.TIE_AWARE_KINDS or p in ("-7", "edge") or method in ("fenwick", "three_split")
-        ok, why = gu.same_rows(data["ids|" + key], data["dists|" + key], ids, dists, tie)
+        ctx = gu.RowContext(data["X"], data["labels"], Q, data["W_" + p], gu.metric_of(gu.FIXTURES[name]))
+        ok, why = gu.same_rows(data["ids|" + key], data["dists|" + key], ids, dists, tie, ctx)
         assert ok, f"{name} {key}: {why}"
         n += 1
     assert n > 0
@@ -129,7 +132,7 @@ def test_index_matches_oracle(oracle, wa, gpu, tmp_path, kind, sfx, gen, d, n, k
             ids, dists = pi.batch_search(*a, _qp(wa, beam, mult))
             eids, edists = oi.batch_search(*a, _qp(oracle, beam, mult))
             tie = kind in gu.TIE_AWARE_KINDS or p <= -6
-            ok, why = gu.same_rows(eids, edists, ids, dists, tie)
+            ok, why = gu.same_rows(eids, edists, ids, dists, tie, gu.RowContext(X, labels, Q, W, gu.metric_of(sfx)))
             assert ok, f"{kind}{sfx} p={p} beam={beam} mult={mult}: {why}"
             c, oc = pi.counters(), oi.last_counters
             assert c["beam_searches"] == oc["searches"] and c["hops"] == oc["hops"]
@@ -153,7 +156,7 @@ def test_edge_cases(oracle, wa, gpu, tmp_path):
     for beam, mult, mb in [(10, 1, 10000), (16, 2, 10000), (16, 1, 40), (50, 4, 120)]:
         ids, dists = pi.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult, 10, mb))
         eids, edists = oi.batch_search(Q, W, nq, "optimized_postfilter", _qp(oracle, beam, mult, 10, mb))
-        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        ok, why = gu.same_rows(eids, edists, ids, dists, True, gu.RowContext(X, labels, Q, W, "l2"))
         assert ok, why
     assert (ids[0] == 0).all() and (dists[0] == FLT_MAX).all()
     # empty batch and k = 1 / k = 37
@@ -162,7 +165,7 @@ def test_edge_cases(oracle, wa, gpu, tmp_path):
     for k in (1, 37):
         ids, dists = pi.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, 40, 1, k))
         eids, edists = oi.batch_search(Q, W, nq, "optimized_postfilter", _qp(oracle, 40, 1, k))
-        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        ok, why = gu.same_rows(eids, edists, ids, dists, True, gu.RowContext(X, labels, Q, W, "l2"))
         assert ok, why
     # errors: bad shapes raise RuntimeError like the reference (tree_utils.h:46-60)
     with pytest.raises(RuntimeError):
@@ -314,7 +317,7 @@ def test_fenwick_and_three_split_match_oracle(oracle, wa, gpu, tmp_path, sfx, ge
                 for beam, mult, ratio in [(10, 1, None), (20, 3, None), (20, 2, 1.5)]:
                     ids, dists = pi.batch_search(Q, W, nq, method, _qp(wa, beam, mult, ratio=ratio))
                     eids, edists = oi.batch_search(Q, W, nq, method, _qp(oracle, beam, mult, ratio=ratio))
-                    ok, why = gu.same_rows(eids, edists, ids, dists, True)
+                    ok, why = gu.same_rows(eids, edists, ids, dists, True, gu.RowContext(X, labels, Q, W, gu.metric_of(sfx)))
                     assert ok, f"{kind}{sfx} split={split} p={p} {method} beam={beam} x{mult} ratio={ratio}: {why}"
                     if kind.startswith("Vamana"):
                         c, oc = pi.counters(), oi.last_counters
@@ -381,6 +384,130 @@ def test_big_workgroup_levels_return_identical_rows(wa, gpu, monkeypatch):
                     assert c["rounds"] >= 2  # some task doubled beyond the cap: the follow-up launch ran
 
 
+def _continuation_case(wa):
+    n, d, nq = 150000, 64, 1500
+    g = sift_like(n, d, 14)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 16)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, ""))
+    return idx, Q, labels, nq
+
+
+def test_unserved_continuations_are_recovered(wa, gpu, monkeypatch):
+    """Tasks that must double beyond the in-kernel cap after their speculative levels failed are handed to pollers of the
+    companion launch.  Pollers that give up (launches serialised by the runtime or a profiler) leave them in the hand-over
+    list; the host re-queues them for the follow-up launch: same rows, same counters, no error."""
+    idx, Q, labels, nq = _continuation_case(wa)
+    seen_recovery = 0
+    for p, beam, mult in [(-9, 10, 1), (-8, 20, 1), (-7, 40, 2)]:
+        W = windows(labels, nq, p, seed=5)
+        monkeypatch.delenv("WANN_FORCE_POLL_TIMEOUT", raising=False)
+        ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+        c = idx.counters()
+        assert c["recovered_continuations"] == 0
+        monkeypatch.setenv("WANN_FORCE_POLL_TIMEOUT", "1")
+        ids2, dists2 = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+        c2 = idx.counters()
+        monkeypatch.delenv("WANN_FORCE_POLL_TIMEOUT")
+        assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2), (p, beam, mult)
+        assert (c["beam_searches"], c["hops"], c["dist_cmps"]) == (c2["beam_searches"], c2["hops"], c2["dist_cmps"])
+        seen_recovery += c2["recovered_continuations"]
+    assert seen_recovery > 0, "no batch of this test produced a continuation: the recovery path did not run"
+
+
+def test_serialised_kernel_dispatch_is_survived(wa, gpu, tmp_path):
+    """AMD_SERIALIZE_KERNEL=3 makes the runtime run one kernel at a time: the companion launch's pollers can then never
+    meet their producers.  Default behaviour: pollers are not used at all under that setting; with WANN_FORCE_POLLERS the
+    pollers run, notice that the other launch has not started, give up, and the host recovers.  Rows must equal an
+    ordinary run's in both cases (child processes: the runtime reads the variable at start-up)."""
+    import subprocess
+    import sys
+    script = tmp_path / "serial.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {REPO!r}); sys.path.insert(0, os.path.join({REPO!r}, 'tests'))\n"
+        "import rangefilteredann_amd, window_ann as wa\n"
+        "from util import sift_like, distinct_labels, windows\n"
+        "n, d, nq = 150000, 64, 1500\n"
+        "g = sift_like(n, d, 14); X, Q = g(n), g(nq); labels = distinct_labels(n, 16)\n"
+        "idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, sys.argv[1]))\n"
+        "W = windows(labels, nq, -9, seed=5)\n"
+        "ids, dists = idx.batch_search(Q, W, nq, 'optimized_postfilter', wa.QueryParams(10, 10, 1.35, 10**7, 10**4, 1, 10000, None, False))\n"
+        "c = idx.counters()\n"
+        "np.savez(sys.argv[2], ids=ids, dists=dists, rec=c['recovered_continuations'], searches=c['beam_searches'])\n")
+    cache = str(tmp_path / "cache") + "/"
+    os.makedirs(cache)
+    outs = {}
+    for name, env in (("plain", {}), ("serial", {"AMD_SERIALIZE_KERNEL": "3"}), ("serial_pollers", {"AMD_SERIALIZE_KERNEL": "3", "WANN_FORCE_POLLERS": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, str(script), cache, str(tmp_path / (name + ".npz"))], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        outs[name] = np.load(tmp_path / (name + ".npz"))
+    for name in ("serial", "serial_pollers"):
+        assert np.array_equal(outs[name]["ids"], outs["plain"]["ids"]) and np.array_equal(outs[name]["dists"], outs["plain"]["dists"]), name
+        assert int(outs[name]["searches"]) == int(outs["plain"]["searches"])
+    assert int(outs["serial"]["rec"]) == 0  # pollers off: nothing to recover
+
+
+def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
+    """include/wann.h bound with ctypes exactly as INTEGRATION.md shows for a foreign host: create, search (host
+    buffers), counters, destroy -- against the oracle."""
+    import ctypes as C
+    import rangefilteredann_amd
+    lib = C.CDLL(rangefilteredann_amd.lib_path())
+
+    class QP(C.Structure):
+        _fields_ = [("k", C.c_int64), ("beam_width", C.c_int64), ("cut", C.c_double), ("limit", C.c_int64), ("degree_limit", C.c_int64),
+                    ("final_beam_multiply", C.c_int64), ("postfiltering_max_beam", C.c_int64), ("has_ratio", C.c_int32), ("ratio", C.c_float),
+                    ("verbose", C.c_int32)]
+
+    class BP(C.Structure):
+        _fields_ = [("max_degree", C.c_int64), ("limit", C.c_int64), ("alpha", C.c_double), ("cache_path", C.c_char_p)]
+
+    class CTR(C.Structure):
+        _fields_ = [(f, C.c_int64) for f in ("beam_searches", "hops", "dist_cmps", "brute_rows", "label_reads", "rounds", "spec_searches",
+                                            "spec_hops", "spec_dist_cmps", "gemm_queries")] + [("device_ms", C.c_double), ("search_kernel_ms", C.c_double),
+                                                                                              ("recovered_continuations", C.c_int64)]
+
+    lib.wann_index_create.restype = C.c_void_p
+    lib.wann_index_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                      C.POINTER(BP), C.c_int, C.c_int]
+    lib.wann_batch_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(QP), C.c_void_p, C.c_void_p]
+    lib.wann_get_counters.argtypes = [C.c_void_p, C.POINTER(CTR)]
+    lib.wann_index_destroy.argtypes = [C.c_void_p]
+    lib.wann_last_error.restype = C.c_char_p
+    n, d, nq, k = 5000, 48, 200, 10
+    g = sift_like(n, d, 31)
+    X, Q = np.ascontiguousarray(g(n)), np.ascontiguousarray(g(nq))
+    labels = distinct_labels(n, 7)
+    cache = (str(tmp_path) + "/").encode()
+    bp = BP(24, 48, 1.0, cache)
+    h = lib.wann_index_create(3, 0, 0, X.ctypes.data, n, d, labels.ctypes.data, 400, 2.0, 0.5, C.byref(bp), 0, 0)
+    assert h, lib.wann_last_error()
+    oi = oracle.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=400, split_factor=2, build_params=oracle.BuildParams(24, 48, 1.0, cache.decode()))
+    try:
+        for p, method in ((-3, "optimized_postfilter"), (-5, "fenwick"), (-2, "three_split")):
+            W = windows(labels, nq, p, seed=3)
+            W32 = np.ascontiguousarray(W.astype(np.float32))
+            ids = np.zeros((nq, k), dtype=np.uint32)
+            dists = np.zeros((nq, k), dtype=np.float32)
+            qp = QP(k, 20, 1.35, 10**7, 10**4, 2, 10000, 0, 0.0, 0)
+            rc = lib.wann_batch_search(h, Q.ctypes.data, W32.ctypes.data, nq, method.encode(), C.byref(qp), ids.ctypes.data, dists.ctypes.data)
+            assert rc == 0, lib.wann_last_error()
+            eids, edists = oi.batch_search(Q, W, nq, method, _qp(oracle, 20, 2))
+            ok, why = gu.same_rows(eids, edists, ids, dists, method != "optimized_postfilter", gu.RowContext(X, labels, Q, W, "l2"))
+            assert ok, (method, why)
+            ctr = CTR()
+            assert lib.wann_get_counters(h, C.byref(ctr)) == 0
+            assert ctr.beam_searches == oi.last_counters["searches"] and ctr.hops == oi.last_counters["hops"]
+        bad = QP(0, 20, 1.35, 10**7, 10**4, 2, 10000, 0, 0.0, 0)
+        assert lib.wann_batch_search(h, Q.ctypes.data, W32.ctypes.data, nq, b"fenwick", C.byref(bad), ids.ctypes.data, dists.ctypes.data) != 0
+        assert b"k must be" in lib.wann_last_error()
+    finally:
+        lib.wann_index_destroy(h)
+
+
 # ------------------------------------------------------------------------------------------
 # dense prefilter path (queries sharing a window -> MFMA GEMM + exact re-rank), adversarial-style data
 # (generate_datasets/generate_advserial_dataset.py:8-69: clusters, labels c - 0.5 + U(0,1), one window per cluster)
@@ -416,7 +543,7 @@ def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sf
         c = pi.counters()
         assert c["gemm_queries"] > nq // 2, c
         eids, edists = oi.batch_search(Q, W, nq, _qp(oracle, 10, 1, k))
-        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        ok, why = gu.same_rows(eids, edists, ids, dists, True, gu.RowContext(X, labels, Q, W, gu.metric_of(sfx)))
         assert ok, f"{metric} k={k}: {why}"
         monkeypatch.setenv("WANN_NO_GEMM", "1")
         ids2, dists2 = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
@@ -445,7 +572,7 @@ def test_tiny_shapes(oracle, wa, gpu, n, d):
                 a = (Q, W, 9) + (("optimized_postfilter",) if kind.endswith("RangeFilterTreeIndex") else ())
                 ids, dists = pi.batch_search(*a, _qp(wa, beam, mult, 3))
                 eids, edists = oi.batch_search(*a, _qp(oracle, beam, mult, 3))
-                ok, why = gu.same_rows(eids, edists, ids, dists, True)
+                ok, why = gu.same_rows(eids, edists, ids, dists, True, gu.RowContext(X, labels, Q, W, gu.metric_of(sfx)))
                 assert ok, f"n={n} d={d} {kind}{sfx} beam={beam} x{mult}: {why}"
 
 
@@ -459,7 +586,7 @@ def test_prefilter_classes_accept_beam_zero(oracle, wa, gpu):
     for cls, args in (("PrefilterIndexFloatEuclidian", ()), ("RangeFilterTreeIndexFloatEuclidian", ("fenwick",))):
         ids, dists = getattr(wa, cls)(X, labels).batch_search(Q, W, nq, *args, _qp(wa, 0, 1, 10))
         eids, edists = getattr(oracle, cls)(X, labels).batch_search(Q, W, nq, *args, _qp(oracle, 0, 1, 10))
-        ok, why = gu.same_rows(eids, edists, ids, dists, True)
+        ok, why = gu.same_rows(eids, edists, ids, dists, True, gu.RowContext(X, labels, Q, W, "l2"))
         assert ok, f"{cls}: {why}"
     with pytest.raises(RuntimeError, match="beam_width must be positive"):
         wa.PostfilterVamanaIndexFloatEuclidian(X, labels, wa.BuildParams(8, 16, 1.0, "")).batch_search(Q, W, nq, _qp(wa, 0, 1, 10))

@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --nq queries per GPU; strong: ONE --nq-query batch cut across the GPUs")
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n", "--points", dest="n", type=int, default=1_000_000)  # (--points: "--n" is an ambiguous prefix for torch.distributed.run)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--fraction", type=int, default=-3, help="headline window fraction exponent")

@@ -127,6 +127,13 @@ struct SearchArgs {
   int32_t *out_cnt;             // [ntasks]
   int32_t *g_table;             // per wave slot seen-filter, 4 << g_table_bits bytes each (or null)
   int32_t g_table_bits;
+  // wave_beam_search_big (beam in the LDS, filter in g_table): filter entries are tagged with the slot's search epoch
+  // (g_epoch[slot], 1..254; the host zeroes table + epochs together), and the exact set of scored nodes is a bitmap of
+  // g_seen_words 32-bit words per slot (>= largest partition / 32, a multiple of 4)
+  int32_t *g_epoch;
+  uint32_t *g_seen;
+  int64_t g_seen_words;
+  int32_t old_general;          // dev / test: the first-generation general core (wave_beam_search) instead
   unsigned long long *g_beam;   // per wave slot beam, g_beam_cap entries each (or null)
   int64_t g_beam_cap;
   Counters *ctr;

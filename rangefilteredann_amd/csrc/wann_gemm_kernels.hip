@@ -179,12 +179,6 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
 // one wave per grouped query: the kSelect best scores of its row of S
 #undef WANN_FETCH
 
-// lane i receives lane i-1's value (DPP wave_shr:1; lane 0 keeps its own)
-__device__ __forceinline__ u64 wave_shr1(u64 v) {
-  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
-  return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
-}
 
 // One wave per grouped query.  The kSelect best (score, position) keys live sorted in the registers of
 // lanes 0 .. kSelect-1; a row is streamed 1024 scores at a time (four 16-byte loads per lane in flight)

@@ -68,6 +68,11 @@ struct Workspace {
   DevBuf<Task> tasks;
   DevBuf<int32_t> list_a, list_b, list_final, list_heavy, list_mid, list_big, list_brute, ints, out_cnt, g_table, g_table_big, qtask_cnt, next_beam;
   DevBuf<unsigned long long> out_key, g_beam;
+  // wave_beam_search_big: per-slot exact seen bitmaps and filter epochs for the ordinary / follow-up launches
+  // (g_table) and for the companion launch (g_table_big); a table and its epochs are zeroed together
+  DevBuf<uint32_t> g_seen, g_seen_big, g_seen_f;
+  DevBuf<int32_t> g_epoch, g_epoch_big, g_epoch_f, g_table_f;  // (_f: follow-up launches, whose slot layout varies)
+  int64_t g_table_layout = -1, g_table_big_layout = -1, g_table_f_layout = -1;  // (slots << 8 | bits) of the last use
   DevBuf<long long> sub_hops, sub_cmps;
   DevBuf<int32_t> par_done;
   DevBuf<Counters> ctr;
@@ -270,6 +275,24 @@ void upload_index(wann_index &I) {
   }
   I.device_bytes = (int64_t)(I.d_points.bytes() + I.d_labels.bytes() + I.d_decoding.bytes() + I.d_graph.bytes() +
                              I.d_parts.bytes() + I.d_fv.bytes() + I.d_fi.bytes() + I.d_wst_off.bytes());
+}
+
+// Global scratch of a launch whose searches keep their seen-filter in global memory: the per-slot filter tables
+// (entries tagged with the slot's search epoch), the epochs, and the per-slot exact seen bitmaps.  A table whose
+// slot layout changes (or that was reallocated) is zeroed together with its epochs.
+void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBuf<uint32_t> &seen, int64_t &layout, int slots,
+                           int table_bits, int64_t seen_words, hipStream_t st) {
+  const size_t need = (size_t)slots << table_bits;
+  const int64_t want = ((int64_t)slots << 8) | table_bits;
+  const bool fresh = need > table.cap || (size_t)slots > epoch.cap;
+  table.ensure(need);
+  epoch.ensure((size_t)slots);
+  seen.ensure((size_t)slots * (size_t)seen_words);
+  if (fresh || layout != want) {
+    HIP_CHECK(hipMemsetAsync(table.p, 0, table.cap * sizeof(int32_t), st));
+    HIP_CHECK(hipMemsetAsync(epoch.p, 0, epoch.cap * sizeof(int32_t), st));
+    layout = want;
+  }
 }
 
 struct RoundCfg {
@@ -575,6 +598,10 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     const bool use_pollers = !getenv("WANN_NO_POLLERS") &&
                              (getenv("WANN_FORCE_POLLERS") /* test hook */ ||
                               (!env_on("HIP_LAUNCH_BLOCKING") && !env_on("AMD_SERIALIZE_KERNEL") && !env_on("CUDA_LAUNCH_BLOCKING")));
+    int64_t max_part = 1;
+    for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
+    const int64_t seen_words = ((max_part + 127) / 128) * 4;
+    sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0) {
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds);
       a.B = (int32_t)first_beam;
@@ -606,8 +633,11 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         big_lc.blocks = I.num_cus;
         big_lc.waves_per_block = 1;
         big_lc.big = 1;
-        W.g_table_big.ensure((size_t)big_lc.blocks << big.g_table_bits);
+        ensure_filter_scratch(W.g_table_big, W.g_epoch_big, W.g_seen_big, W.g_table_big_layout, big_lc.blocks, big.g_table_bits, seen_words, st);
         big.g_table = W.g_table_big.p;
+        big.g_epoch = W.g_epoch_big.p;
+        big.g_seen = W.g_seen_big.p;
+        big.g_seen_words = seen_words;
         a.yield_for_big = getenv("WANN_NO_YIELD") ? 0 : 1;
         a.big_count = W.ints.p + I_BIG_COUNT;
         if (use_pollers) {
@@ -622,10 +652,16 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
           HIP_CHECK(hipMemsetAsync(a.dyn_list, 0xFF, (size_t)W.big_stride * sizeof(int32_t), st));
         }
       }
+      a.g_epoch = nullptr;
+      a.g_seen = nullptr;
       if (rc.table_bits) {
-        W.g_table.ensure((size_t)rc.slots << rc.table_bits);
-        a.g_table = W.g_table.p;
+        if (big_lds) ensure_filter_scratch(W.g_table_f, W.g_epoch_f, W.g_seen_f, W.g_table_f_layout, rc.slots, rc.table_bits, seen_words, st);
+        else ensure_filter_scratch(W.g_table, W.g_epoch, W.g_seen, W.g_table_layout, rc.slots, rc.table_bits, seen_words, st);
+        a.g_table = big_lds ? W.g_table_f.p : W.g_table.p;
         a.g_table_bits = rc.table_bits;
+        a.g_epoch = big_lds ? W.g_epoch_f.p : W.g_epoch.p;
+        a.g_seen = big_lds ? W.g_seen_f.p : W.g_seen.p;
+        a.g_seen_words = seen_words;
       }
       if (rc.beam_cap) {
         W.g_beam.ensure((size_t)rc.slots * rc.beam_cap);
@@ -1142,10 +1178,18 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     sa.raw_hops = d_hops.p;
     sa.raw_cmps = d_cmps.p;
     sa.raw_qids = d_qids.p;
+    DevBuf<int32_t> g_epoch;
+    DevBuf<uint32_t> g_seen;
+    int64_t layout = -1;
+    sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
     if (rc.table_bits) {
-      g_table.ensure((size_t)rc.slots << rc.table_bits);
+      const int64_t seen_words = ((subset_n + 127) / 128) * 4;
+      ensure_filter_scratch(g_table, g_epoch, g_seen, layout, rc.slots, rc.table_bits, seen_words, nullptr);
       sa.g_table = g_table.p;
       sa.g_table_bits = rc.table_bits;
+      sa.g_epoch = g_epoch.p;
+      sa.g_seen = g_seen.p;
+      sa.g_seen_words = seen_words;
     }
     if (rc.beam_cap) {
       sa.g_beam_cap = rc.beam_cap;

@@ -54,7 +54,7 @@ __device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:
 // continuations handed over by ordinary waves until every ordinary ticket is done.  Two kernels rather than
 // two modes of one: the mode logic cost the ordinary kernel 20 VGPRs (it needs all 256 of two waves per SIMD).
 template <int METRIC, bool BIG>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A) {  // (two waves per SIMD: at most 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id();
@@ -172,12 +172,44 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_search(SearchArgs A) {
           mini = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(L.lbeam) + beam_bytes);
           mini_mask = (1u << (31 - __builtin_clz((unsigned)free_words))) - 1u;
         }
-        wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
-                                                     nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask);
+        if (A.g_seen && !A.old_general) {
+          // tagged filter entries: this search takes the slot's next epoch; on wrap-around (or after a search that stored
+          // plain ids) the slot's whole region is zeroed.  Partitions of more than 2^24 nodes use plain ids.
+          int e = 0;
+          if (lane == 0) e = A.g_epoch[slot];
+          e = uni(e);
+          uint32_t tag = 0;
+          if (part.n <= (1 << 24)) {
+            if (e >= 254) {
+              int4 *gt = reinterpret_cast<int4 *>(gtable);
+              for (int i = lane; i < (1 << (A.g_table_bits - 2)); i += 64) gt[i] = make_int4(0, 0, 0, 0);
+              e = 0;
+            }
+            e++;
+            tag = (uint32_t)e << 24;
+          } else {
+            int4 *gt = reinterpret_cast<int4 *>(gtable);
+            for (int i = lane; i < (1 << (bits - 2)); i += 64) gt[i] = make_int4(-1, -1, -1, -1);
+            e = 254;
+          }
+          if (lane == 0) A.g_epoch[slot] = e;
+          if (!mini) {  // no room beside the beam: the merge scratch (unused during the filter step) serves
+            mini = reinterpret_cast<int32_t *>(L.cand_key);
+            mini_mask = 127u;
+          }
+          wave_beam_search_big<METRIC>(ix, part, L, gtable, tag, A.g_seen + (size_t)slot * A.g_seen_words, B, bits, qid, A.limit,
+                                       A.degree_limit, mini, mini_mask, m, nvis, ncmp, A.prof);
+        } else {
+          if (A.g_epoch && lane == 0) A.g_epoch[slot] = 254;  // plain ids go into the table: the next tagged search clears it
+          wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
+                                                       nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask);
+        }
       }
-      else
+      else {
+        if (A.g_epoch && lane == 0) A.g_epoch[slot] = 254;
         wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
                                                       nullptr, 0, m, nvis, ncmp, A.prof);
+      }
       auto beam_ld = [&](int i) -> u64 { return beam_lds ? L.lbeam[i] : gbeam[i]; };
 #ifdef WANN_TASK_TRACE
       if (A.trace && lane == 0) {

@@ -12,6 +12,14 @@ namespace wann {
 
 typedef unsigned long long u64;
 
+// Per-phase cycle accounting of the search cores is a compile-time option (make PROFILE=1, dev tool
+// tools/phase_profile.py): its accumulators cost the production kernels a dozen scalar registers.
+#ifdef WANN_PHASE_PROFILE
+#define WANN_PROF_PTR(p) (p)
+#else
+#define WANN_PROF_PTR(p) ((unsigned long long *)nullptr)
+#endif
+
 #define WAVE_SYNC()                                            \
   do {                                                         \
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     \
@@ -365,19 +373,21 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
 // position of the first inserted element (or the old size when nothing was inserted).
 // cand_key: 64 u64 of per-wave LDS scratch.
 // --------------------------------------------------------------------------------------------
-template <typename BeamPtr, bool DEDUP = true>
+// PRESORTED: the candidates sit in lanes 0..c-1 in ascending key order already (no ranking pass).
+template <typename BeamPtr, bool DEDUP = true, bool PRESORTED = false>
 __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass, u64 key,
                                           u64 *cand_key, int *first_pos) {
   const int lane = lane_id();
   *first_pos = m;
   u64 smask = ballot64(pass);
   if (smask == 0) return m;
-  int rank = 0;
-  for (u64 mm = smask; mm; mm &= mm - 1) {
-    int l = ctz64(mm);
-    u64 kl = rdlane64(key, l);
-    rank += (kl < key || (kl == key && l < lane)) ? 1 : 0;
-  }
+  int rank = PRESORTED ? lane : 0;
+  if (!PRESORTED)
+    for (u64 mm = smask; mm; mm &= mm - 1) {
+      int l = ctz64(mm);
+      u64 kl = rdlane64(key, l);
+      rank += (kl < key || (kl == key && l < lane)) ? 1 : 0;
+    }
   if (pass) cand_key[rank] = key;
   WAVE_SYNC();
   const int c = popc64(smask);
@@ -526,6 +536,7 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
                                                  int &m_out, long long &nvis_out, long long &ncmp_out,
                                                  unsigned long long *prof = nullptr, int32_t *mini = nullptr,
                                                  uint32_t mini_mask = 0) {
+  prof = WANN_PROF_PTR(prof);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = part.start;
@@ -672,6 +683,275 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
 
 
 // --------------------------------------------------------------------------------------------
+// General beam-search core for beams that do not fit the register-resident variant (B > 128): the same
+// search as wave_beam_search<.., false, true, false> (beam in the LDS, lossy seen-filter in global memory)
+// with the three per-hop costs of that routine removed from the chain of dependent hops:
+//
+//  * EXACT SEEN SET.  Besides the reference's lossy filter (beamSearch.h:66-73, kept bit for bit: it decides
+//    which neighbours the reference scores, i.e. the dist_cmps counter) the search keeps an exact bitmap of
+//    the nodes it has scored.  Scoring a node a second time can never change the beam: its distance is the
+//    same; either it is still in the beam (std::set_union drops the copy, :151-154) or it was cut off / never
+//    admitted at a cutoff that has only decreased since (:135-145), so `d < cutoff` fails again.  Re-scores
+//    are therefore COUNTED (dist_cmps) but not computed, and every candidate that is computed is new: the
+//    union needs no duplicate test.  (Rows that list a node twice are the one exception -- the reference's
+//    multiset union can then keep two copies -- and take the old exact path.)
+//  * DELTA LIST.  New entries go into a sorted 64-entry list in REGISTERS (one key per lane; a DPP lane
+//    shift per insertion); the LDS beam is merged with it only when the list is full.  The beam is the
+//    union of the two; it is kept truncated to B eagerly (the larger of the two last entries leaves), so
+//    the cutoff is the larger of two scalar values.  No O(B) shift per hop.
+//  * TAGGED FILTER ENTRIES.  A filter entry is (epoch << 24 | id): a search invalidates its predecessor's
+//    entries by taking the next epoch instead of clearing up to 32 MiB.
+//
+// Results, hops and dist_cmps are those of wave_beam_search (the parity tests run both against the oracle).
+// On return the whole beam is in L.lbeam[0..m).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 wave_shr1(u64 v) {  // lane i receives lane i-1's value (DPP wave_shr:1); lane 0 keeps its own
+  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+  return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+template <int METRIC>
+__device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const PartDesc &part, const WaveLds &L,
+                                                     int32_t *gtable, uint32_t tag, uint32_t *gseen, int B, int bits,
+                                                     int64_t qid, int64_t limit, int degree_limit, int32_t *mini,
+                                                     uint32_t mini_mask, int &m_out, long long &nvis_out,
+                                                     long long &ncmp_out, unsigned long long *prof = nullptr) {
+  prof = WANN_PROF_PTR(prof);
+  const int lane = lane_id();
+  const uint32_t tmask = (1u << bits) - 1u;
+  const int64_t row_off = part.start;
+  u64 *const mb = L.lbeam;
+  {  // exact seen set of this search: empty
+    int4 *sv = reinterpret_cast<int4 *>(gseen);
+    const int n16 = (part.n + 127) >> 7;
+    for (int i = lane; i < n16; i += 64) sv[i] = make_int4(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in L2 before the first probe (probes and updates are L2 atomics)
+  }
+  // frontier = {start node 0} (beamSearch.h:80-82); the start node counts as scored
+  if (lane == 0) L.cand_id[0] = 0;
+  WAVE_SYNC();
+  float d0 = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, 1, row_off);
+  d0 = __shfl(d0, 0);
+  if (lane == 0) {
+    mb[0] = (u64)fkey(d0) << 32;
+    __hip_atomic_fetch_or(gseen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  WAVE_SYNC();
+  int M = 1, D = 0;            // entries in the LDS beam / in the delta list
+  u64 dk = ~0ull;              // delta list: lane i < D holds its i-th smallest key; ~0 elsewhere
+  int pm = 0;                  // first unvisited entry of the LDS beam (M: none)
+  u64 pmk = (u64)fkey(d0) << 32;  // its key (~0: none)
+  u64 mlk = pmk;               // key of the last entry of the LDS beam, mb[M - 1] (0: empty)
+  int nvis = 0, ncmp = 1;
+  const int lim = limit > 0x7fffffff ? 0x7fffffff : (int)limit;
+  auto load_last = [&]() {
+    u64 v = 0;
+    if (M > 0) v = mb[M - 1];  // uniform address: an LDS broadcast
+    mlk = rdlane64(v, 0);
+  };
+  auto rescan = [&](int s) {  // pm = first unvisited entry at or after s
+    pm = M;
+    pmk = ~0ull;
+    while (s < M) {
+      const int x = s + lane;
+      const u64 v = x < M ? mb[x] : 1ull;
+      const u64 um = ballot64(!(v & 1ull));
+      if (um) {
+        const int i = ctz64(um);
+        pm = s + i;
+        pmk = rdlane64(v, i);
+        break;
+      }
+      s += 64;
+    }
+  };
+  auto flush = [&]() {  // merge the delta list into the LDS beam
+    if (D == 0) return;
+    int p0;
+    M = wave_merge<u64 *, false, true>(mb, M, B, lane < D, dk, L.cand_key, &p0);
+    D = 0;
+    dk = ~0ull;
+    load_last();
+    rescan(pm < p0 ? pm : p0);
+  };
+
+  unsigned long long tp = 0, acc[6] = {0, 0, 0, 0, 0, 0};
+#define WANN_PHASE(i)                                       \
+  do {                                                      \
+    if (prof) {                                             \
+      unsigned long long tn = __builtin_readcyclecounter(); \
+      acc[i] += tn - tp;                                    \
+      tp = tn;                                              \
+    }                                                       \
+  } while (0)
+  if (prof) tp = __builtin_readcyclecounter();
+  for (;;) {
+    // ---- visit the closest unvisited entry of the beam (beamSearch.h:108-117): the closer of the first unvisited
+    //      entry of the LDS beam and the first unvisited entry of the delta list
+    const u64 du = ballot64(lane < D && !(dk & 1ull));
+    if ((pmk == ~0ull && du == 0) || nvis >= lim) break;
+    int cur = 0;
+    bool from_delta = false;
+    if (du) {
+      const int dl = ctz64(du);
+      const u64 dkey = rdlane64(dk, dl);
+      if ((dkey | 1ull) < (pmk | 1ull)) {
+        from_delta = true;
+        cur = (int)((uint32_t)dkey >> 1);
+        if (lane == dl) dk |= 1ull;
+      }
+    }
+    if (!from_delta) {
+      cur = (int)((uint32_t)pmk >> 1);
+      if (lane == 0) mb[pm] = pmk | 1ull;
+    }
+    nvis++;
+    // ---- adjacency row, coalesced (graph.h:198); -1 = unused slot
+    int a = -1;
+    if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
+    if (!from_delta) {  // (LDS only: overlaps the row's flight)
+      WAVE_SYNC();
+      rescan(pm + 1);
+    }
+    const bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+    if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WANN_PHASE(0);  // row fetch
+
+    // ---- lossy seen-filter (sequential semantics, beamSearch.h:68-73,126-131) + exact seen set
+    const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
+    const int tagged = (int)(tag | (uint32_t)a);
+    int old = -1;
+    uint32_t sw = 0;
+    if (valid) {
+      old = gtable[loc];
+      sw = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // exact test "two valid lanes of the row share a filter slot": every lane tags its slot of a small LDS hash with
+    // its lane number; a lane that lost its slot compares filter slots with the winner, and the few lanes whose
+    // loss was a collision of the small hash only are compared with all lanes
+    const uint32_t mh = loc & mini_mask;
+    if (valid) mini[mh] = lane;
+    WAVE_SYNC();
+    const int mw = valid ? mini[mh] : lane;
+    WAVE_SYNC();
+    const uint32_t loc_w = (uint32_t)__shfl((int)loc, mw);
+    const bool lost = valid && (mw != lane);
+    bool clash = ballot64(lost && loc_w == loc) != 0;
+    for (u64 um = ballot64(lost && loc_w != loc); um && !clash; um &= um - 1) {
+      const int u = ctz64(um);
+      const uint32_t lu = (uint32_t)rdlane((int)loc, u);
+      clash = ballot64(valid && loc == lu && lane != u) != 0;
+    }
+    bool seen, twice = false;
+    if (!clash) {
+      seen = valid && (old == tagged);
+      if (valid) gtable[loc] = tagged;
+    } else {  // exact emulation of the sequential rule (as in wave_beam_search)
+      u64 eq = ballot64(valid);
+      for (int b = 0; b < bits; b++) {
+        const bool bit = (loc >> b) & 1u;
+        const u64 bm = ballot64(valid && bit);
+        eq &= bit ? bm : ~bm;
+      }
+      const u64 lower = valid ? (eq & lanemask_lt()) : 0ull;
+      const u64 higher = (lane == 63) ? 0ull : (eq >> (lane + 1));
+      const int prev_lane = lower ? (63 - __builtin_clzll(lower)) : lane;
+      const int prev_val = __shfl(a, prev_lane);
+      seen = valid && (lower ? (prev_val == a) : (old == tagged));
+      WAVE_SYNC();
+      if (valid && higher == 0) gtable[loc] = tagged;
+      // does the row list one node twice (the reference's builder can append the start point twice)?
+      u64 lm = lower;
+      while (ballot64(lm != 0)) {
+        const int l = lm ? (63 - __builtin_clzll(lm)) : lane;
+        const int v = __shfl(a, l);
+        if (lm && v == a) twice = true;
+        if (lm) lm &= ~((u64)1 << l);
+      }
+      twice = ballot64(twice) != 0;
+    }
+    const bool kept = valid && !seen;  // what the reference scores
+    ncmp += popc64(ballot64(kept));
+    const bool fresh = kept && !((sw >> (a & 31)) & 1u);
+    const bool take = twice ? kept : fresh;  // what is computed
+    if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 tmask64 = ballot64(take);
+    const int nt = popc64(tmask64);
+    if (take) L.cand_id[popc64(tmask64 & lanemask_lt())] = a;
+    WAVE_SYNC();
+    WANN_PHASE(1);  // seen-filter
+
+    if (twice) flush();  // the exact multiset union below works on the whole beam
+    // ---- score (beamSearch.h:135-145)
+    float cutoff = 2147483648.0f;  // (float)INT_MAX
+    if (M + D >= B) {
+      const u64 dlast = D ? rdlane64(dk, D - 1) : 0ull;
+      cutoff = funkey((uint32_t)(((mlk | 1ull) > (dlast | 1ull) ? mlk : dlast) >> 32));
+    }
+    const float dist = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, nt, row_off);
+    const int cid = (lane < nt) ? L.cand_id[lane] : 0;
+    WAVE_SYNC();
+    const bool pass = (lane < nt) && (dist < cutoff);
+    const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);
+    WANN_PHASE(2);  // vector fetch + distances
+
+    // ---- union + truncate (beamSearch.h:148-157)
+    if (twice) {
+      int p0;
+      M = wave_merge(mb, M, B, pass, key, L.cand_key, &p0);
+      load_last();
+      rescan(pm < p0 ? pm : p0);
+    } else {
+      // the last entries of the LDS beam (they leave one by one while the beam is full): lane j holds mb[tbase - 1 - j]
+      const u64 pmask = ballot64(pass);
+      int tbase = 0;
+      u64 tailv = 0;
+      auto load_chunk = [&]() {
+        tbase = M;
+        const int x = M - 1 - lane;
+        tailv = x >= 0 ? mb[x] : 0ull;
+      };
+      if (pmask && M + D + popc64(pmask) > B) load_chunk();
+      for (u64 mm = pmask; mm; mm &= mm - 1) {
+        const u64 k = rdlane64(key, ctz64(mm));
+        if (M + D == B) {  // full: the largest entry leaves
+          const u64 dlast = D ? rdlane64(dk, D - 1) : 0ull;
+          if ((mlk | 1ull) > (dlast | 1ull)) {
+            M--;
+            if (tbase - M >= 64) load_chunk();
+            mlk = M > 0 ? rdlane64(tailv, tbase - M) : 0ull;
+            if (pm >= M) {
+              pm = M;
+              pmk = ~0ull;
+            }
+          } else {
+            D--;
+            if (lane == D) dk = ~0ull;
+          }
+        }
+        if (D == 64) {
+          flush();
+          load_chunk();
+        }
+        const int pos = popc64(ballot64(lane < D && (dk | 1ull) < (k | 1ull)));
+        const u64 up = wave_shr1(dk);
+        dk = lane < pos ? dk : (lane == pos ? k : up);
+        D++;
+      }
+    }
+    WANN_PHASE(3);  // insertion
+  }
+#undef WANN_PHASE
+  flush();
+  if (prof && lane == 0)
+    for (int i = 0; i < 5; i++) atomicAdd(&prof[i], acc[i]);
+  m_out = M;
+  nvis_out = nvis;
+  ncmp_out = ncmp;
+}
+
+// --------------------------------------------------------------------------------------------
 // Register-resident variant (B <= 64 * NE, seen-filter in LDS): the beam lives in registers for the
 // whole search, entry x in lane x % 64, slot x / 64.  The union with the scored candidates is
 // computed by ONE loop over the passing candidates in which every lane compares its beam entries
@@ -685,6 +965,7 @@ __device__ __forceinline__ void wave_beam_search_small(const IndexView &ix, cons
                                                        int B, int bits, int64_t qid, int64_t limit, int degree_limit,
                                                        int &m_out, long long &nvis_out, long long &ncmp_out,
                                                        unsigned long long *prof = nullptr) {
+  prof = WANN_PROF_PTR(prof);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   constexpr uint32_t TAG = 0x80000000u;

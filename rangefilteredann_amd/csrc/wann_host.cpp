@@ -297,6 +297,7 @@ void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBu
 
 struct RoundCfg {
   LaunchCfg lc;
+  bool big_lds;      // the one-wave-per-workgroup kernel
   int slots;
   int pool_bytes;    // per-wave LDS pool of this launch
   int table_bits;    // per-slot global seen-filter of 4 << table_bits bytes (0 = none needed)
@@ -306,10 +307,14 @@ struct RoundCfg {
 // Launch geometry for a k_search launch whose searches run beams in [first_beam, cap].
 // big_lds: the rare follow-up launch for beams beyond the in-kernel cap -- one wave per workgroup with a
 // pool large enough to keep even a 10 000-entry beam in the LDS (only its seen-filter lives in global memory).
-RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false) {
+// The four-wave kernel holds the register-resident cores and the second-generation general core only (256 registers per
+// wave); everything else -- beams whose LDS beam exceeds the four-wave pool, the first-generation cores behind the test
+// switches -- runs in the one-wave-per-workgroup kernel (big_lds).  force_table: a global seen-filter even if the LDS would do.
+RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false) {
   RoundCfg rc{};
-  const int wpb = big_lds ? 1 : kWavesPerBlock;
   const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
+  if (cap_bytes > kSearchPoolBytes) big_lds = true;
+  const int wpb = big_lds ? 1 : kWavesPerBlock;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
   int pool = kSearchPoolBytes;
   if (big_lds) pool = (int)std::min<int64_t>(std::max<int64_t>(cap_bytes, kSearchPoolBytes), 150 * 1024 - common);
@@ -321,7 +326,7 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   blocks_per_cu = std::max(1, blocks_per_cu);
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
   const int cap_bits = hash_bits(cap);
-  if (cap_bytes + ((int64_t)4 << cap_bits) > pool) {  // some beam of the range keeps its filter in global memory
+  if (force_table || cap_bytes + ((int64_t)4 << cap_bits) > pool) {  // some beam of the range keeps its filter in global memory
     rc.table_bits = cap_bits;
     int64_t per_slot = (int64_t)4 << cap_bits;
     int64_t max_slots = std::max<int64_t>(wpb, ((int64_t)16 << 30) / per_slot);
@@ -332,6 +337,8 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   blocks = std::min<int64_t>(blocks, (work_items + wpb - 1) / wpb);
   rc.lc.blocks = (int)std::max<int64_t>(blocks, 1);
   rc.lc.waves_per_block = wpb;
+  rc.lc.big = big_lds ? 1 : 0;
+  rc.big_lds = big_lds;
   rc.slots = rc.lc.blocks * wpb;
   return rc;
 }
@@ -603,7 +610,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
     sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0) {
-      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds);
+      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0);
+      big_lds = rc.big_lds;
+      a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
       a.B = (int32_t)first_beam;
       a.cap_inkernel = (int32_t)cap;
       a.pool_bytes = rc.pool_bytes;
@@ -1151,7 +1160,9 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     I.view.rs = rs;
     I.view.maxdeg = (int32_t)maxdeg;
     I.view.metric = metric;
-    RoundCfg rc = config_for(I, beam, beam, nq, getenv("WANN_RAW_BIG_LDS") != nullptr);  // (dev: the large-LDS one-wave configuration)
+    const bool old_general = getenv("WANN_OLD_GENERAL") != nullptr, force_general = getenv("WANN_FORCE_GENERAL") != nullptr;
+    // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
+    RoundCfg rc = config_for(I, beam, beam, nq, getenv("WANN_RAW_BIG_LDS") != nullptr || old_general, force_general);
     DevBuf<int32_t> g_table;
     DevBuf<unsigned long long> g_beam;
     SearchArgs sa{};
@@ -1166,7 +1177,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     sa.max_beam = INT32_MAX;
     sa.mult = 1;
     sa.pool_bytes = rc.pool_bytes;
-    sa.force_general = getenv("WANN_FORCE_GENERAL") ? 1 : 0;
+    sa.force_general = force_general ? 1 : 0;
     sa.k = 1;
     sa.limit = limit;
     sa.degree_limit = (int32_t)std::min<int64_t>(degree_limit, INT32_MAX);
@@ -1181,7 +1192,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     DevBuf<int32_t> g_epoch;
     DevBuf<uint32_t> g_seen;
     int64_t layout = -1;
-    sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
+    sa.old_general = old_general ? 1 : 0;
     if (rc.table_bits) {
       const int64_t seen_words = ((subset_n + 127) / 128) * 4;
       ensure_filter_scratch(g_table, g_epoch, g_seen, layout, rc.slots, rc.table_bits, seen_words, nullptr);

@@ -54,7 +54,7 @@ __device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:
 // continuations handed over by ordinary waves until every ordinary ticket is done.  Two kernels rather than
 // two modes of one: the mode logic cost the ordinary kernel 20 VGPRs (it needs all 256 of two waves per SIMD).
 template <int METRIC, bool BIG>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A) {  // (two waves per SIMD: at most 256 VGPRs)
+__global__ __launch_bounds__(BIG ? 64 : 64 * kWavesPerBlock, BIG ? 1 : 2) void k_search(SearchArgs A) {  // (!BIG: two waves per SIMD, at most 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id();
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
   const int total = mid_end + *A.list_count;  // ordinary tickets
   const int pool_bytes = A.pool_bytes, cap = A.cap_inkernel;
   // BIG: the first npollers workgroups only serve continuations, so that one starts as soon as it is handed over
-  bool polling = BIG && (int)blockIdx.x < A.npollers;
+  bool polling = BIG && A.big_list && (int)blockIdx.x < A.npollers;
   if (BIG && polling && A.big_count[0] + A.big_count[1] == 0) return;  // (pollers only in batches that have big levels at all)
   // ordinary launch with a companion: as many ordinary workgroups as there are big items (+ pollers) leave at once, so that
   // the companion's workgroups (launched first, but the LDS of every CU is fully booked by this launch) find room
@@ -81,12 +81,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
   for (;;) {
     int ti;
     bool dyn = false;
-    if (BIG && !polling) {
+    if (BIG && !polling && A.big_list) {
       const int big_first = A.big_count[0], big_total = big_first + A.big_count[1];
       const int t = wave_ticket(A.big_cursor);
       if (t >= big_total) break;
       ti = (t < big_first) ? A.big_list[t] : A.big_list[A.big_stride + t - big_first];
-    } else if (BIG) {
+    } else if (BIG && polling) {
       // wait for continuation number d, or for the end of all ordinary work (a producer publishes its item
       // before it reports its ticket done, so the item count is final once done_count == total)
       const int d = wave_ticket(A.dyn_cursor);
@@ -127,19 +127,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       if (t >= total) break;
       ti = (t < heavy) ? A.heavy_list[t] : (t < mid_end) ? A.mid_list[t - heavy] : A.list[t - mid_end];  // long searches start first
     }
-    Task task = A.tasks[ti];
-    const PartDesc part = ix.parts[task.part];
-    const int64_t qrow = task.query;
+    // (the task's fields are read where they are used, not kept in scalar registers across the searches)
+    const PartDesc part = ix.parts[A.tasks[ti].part];
+    const int64_t qrow = A.tasks[ti].query;
     const int64_t qid = A.raw ? A.raw_qids[qrow] : (A.qid_base + qrow);
     const int64_t row_off = part.start;
 
     long long b = A.B;
     bool final_pass = A.is_final != 0;
-    bool sub = (task.flags & 4) != 0;  // speculative sub-task: ONE search at beam B << level
+    bool sub = (A.tasks[ti].flags & 4) != 0;  // speculative sub-task: ONE search at beam B << level
     if (BIG && dyn) {  // a continuation: a plain task or a resolved parent, at the beam its producer recorded
       sub = false;
       b = __hip_atomic_load(A.next_beam + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (sub) b = (long long)A.B << (int)task.a;
+    } else if (sub) b = (long long)A.B << (int)A.tasks[ti].a;
     else if (A.start_beam) b = A.start_beam[ti];
     for (;;) {  // postfilter_vamana.h:161-181
       const int B = (int)b;
@@ -156,59 +156,65 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
 #ifdef WANN_TASK_TRACE
       const long long trace_t0 = A.trace ? (long long)wall_clock64() : 0;
 #endif
-      if (table_lds && B <= 64 && !A.force_general)
+      // the part of the pool that the beam leaves free serves as the clash-detection scratch of the general cores
+      int32_t *mini = nullptr;
+      uint32_t mini_mask = 0;
+      const int free_words = beam_lds ? (pool_bytes - beam_bytes) >> 2 : 0;
+      if (free_words >= 1024 && !A.force_general) {
+        mini = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(L.lbeam) + beam_bytes);
+        mini_mask = (1u << (31 - __builtin_clz((unsigned)free_words))) - 1u;
+      }
+      const bool small_ok = table_lds && !A.force_general;
+      if (small_ok && B <= 64)
         wave_beam_search_small<METRIC, 1>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
-      else if (table_lds && B <= 128 && !A.force_general)
+      else if (small_ok && B <= 128)
         wave_beam_search_small<METRIC, 2>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
-      else if (table_lds)
-        wave_beam_search<METRIC, true, true, false>(ix, part, L, nullptr, nullptr, B, bits, qid, A.limit, A.degree_limit,
-                                                    nullptr, 0, m, nvis, ncmp, A.prof);
-      else if (beam_lds) {
-        // the part of the pool that the beam leaves free serves as the clash-detection scratch
-        int32_t *mini = nullptr;
-        uint32_t mini_mask = 0;
-        const int free_words = (pool_bytes - beam_bytes) >> 2;
-        if (free_words >= 1024 && !A.force_general) {
-          mini = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(L.lbeam) + beam_bytes);
-          mini_mask = (1u << (31 - __builtin_clz((unsigned)free_words))) - 1u;
-        }
-        if (A.g_seen && !A.old_general) {
-          // tagged filter entries: this search takes the slot's next epoch; on wrap-around (or after a search that stored
-          // plain ids) the slot's whole region is zeroed.  Partitions of more than 2^24 nodes use plain ids.
-          int e = 0;
-          if (lane == 0) e = A.g_epoch[slot];
-          e = uni(e);
-          uint32_t tag = 0;
-          if (part.n <= (1 << 24)) {
-            if (e >= 254) {
-              int4 *gt = reinterpret_cast<int4 *>(gtable);
-              for (int i = lane; i < (1 << (A.g_table_bits - 2)); i += 64) gt[i] = make_int4(0, 0, 0, 0);
-              e = 0;
-            }
-            e++;
-            tag = (uint32_t)e << 24;
-          } else {
+      else if (beam_lds && A.g_seen && !(BIG && A.old_general)) {
+        // Second-generation general core.  Tagged filter entries: this search takes the slot's next epoch; on
+        // wrap-around (or after a search that stored plain ids) the slot's whole region is zeroed.  Partitions of
+        // more than 2^24 nodes use plain ids and clear what they use.
+        int e = 0;
+        if (lane == 0) e = A.g_epoch[slot];
+        e = uni(e);
+        uint32_t tag = 0;
+        if (part.n <= (1 << 24)) {
+          if (e >= 254) {
             int4 *gt = reinterpret_cast<int4 *>(gtable);
-            for (int i = lane; i < (1 << (bits - 2)); i += 64) gt[i] = make_int4(-1, -1, -1, -1);
-            e = 254;
+            for (int i = lane; i < (1 << (A.g_table_bits - 2)); i += 64) gt[i] = make_int4(0, 0, 0, 0);
+            e = 0;
           }
-          if (lane == 0) A.g_epoch[slot] = e;
-          if (!mini) {  // no room beside the beam: the merge scratch (unused during the filter step) serves
-            mini = reinterpret_cast<int32_t *>(L.cand_key);
-            mini_mask = 127u;
-          }
-          wave_beam_search_big<METRIC>(ix, part, L, gtable, tag, A.g_seen + (size_t)slot * A.g_seen_words, B, bits, qid, A.limit,
-                                       A.degree_limit, mini, mini_mask, m, nvis, ncmp, A.prof);
+          e++;
+          tag = (uint32_t)e << 24;
         } else {
-          if (A.g_epoch && lane == 0) A.g_epoch[slot] = 254;  // plain ids go into the table: the next tagged search clears it
+          int4 *gt = reinterpret_cast<int4 *>(gtable);
+          for (int i = lane; i < (1 << (bits - 2)); i += 64) gt[i] = make_int4(-1, -1, -1, -1);
+          e = 254;
+        }
+        if (lane == 0) A.g_epoch[slot] = e;
+        if (!mini) {  // no room beside the beam: the merge scratch (unused during the filter step) serves
+          mini = reinterpret_cast<int32_t *>(L.cand_key);
+          mini_mask = 127u;
+        }
+        wave_beam_search_big<METRIC>(ix, part, L, gtable, tag, A.g_seen + (size_t)slot * A.g_seen_words, B, bits, qid, A.limit,
+                                     A.degree_limit, mini, mini_mask, m, nvis, ncmp, A.prof);
+      } else if (BIG) {
+        // First-generation general cores: only in the one-wave-per-workgroup kernel (512 registers per wave), which
+        // serves the companion launch, the follow-up launches and the test / dev switches.
+        if (A.g_epoch && lane == 0) A.g_epoch[slot] = 254;  // plain ids go into the table: the next tagged search clears it
+        if (table_lds)
+          wave_beam_search<METRIC, true, true, false>(ix, part, L, nullptr, nullptr, B, bits, qid, A.limit, A.degree_limit,
+                                                      nullptr, 0, m, nvis, ncmp, A.prof);
+        else if (beam_lds)
           wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
                                                        nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask);
-        }
-      }
-      else {
-        if (A.g_epoch && lane == 0) A.g_epoch[slot] = 254;
-        wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
-                                                      nullptr, 0, m, nvis, ncmp, A.prof);
+        else
+          wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
+                                                        nullptr, 0, m, nvis, ncmp, A.prof);
+      } else {
+        // (the host never gives the four-wave kernel a beam that needs one of those: see config_for)
+        m = 0;
+        nvis = ncmp = 0;
+        if (lane == 0) atomicAdd(&A.ctr->unsupported, 1ull);
       }
       auto beam_ld = [&](int i) -> u64 { return beam_lds ? L.lbeam[i] : gbeam[i]; };
 #ifdef WANN_TASK_TRACE
@@ -247,13 +253,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
       //      (postfilter_vamana.h:234-251); ids become sorted-order indices (subset[local])
       int found = 0;
       long long labs = 0;
+      const float win_lo = A.tasks[ti].lo, win_hi = A.tasks[ti].hi;
       for (int bx = 0; bx < m && found < A.k; bx += 64) {
         int x = bx + lane;
         bool act = x < m;
         u64 e = act ? beam_ld(x) : 0ull;
         int lid = (int)((uint32_t)e >> 1);
         float lab = act ? ix.labels[row_off + lid] : 0.f;
-        bool inw = act && (lab >= task.lo) && (lab <= task.hi);
+        bool inw = act && (lab >= win_lo) && (lab <= win_hi);
         u64 im = ballot64(inw);
         int idx = found + popc64(im & lanemask_lt());
         if (inw && idx < A.k)
@@ -271,13 +278,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
         // Publish this level, then the LAST sub-task to finish replays the sequential rule over the
         // levels: the result is that of the first level with >= k in-window entries (or of the last
         // level), exactly what the doubling loop returns; it then continues as the parent.
-        const int parent = (int)task.b;
+        const int parent = (int)A.tasks[ti].b;
         __threadfence();
         int old_done = 0;
         if (lane == 0) old_done = atomicAdd(&A.par_done[parent], 1);
         old_done = uni(old_done);
-        const Task ptask = A.tasks[parent];
-        const int nsub = (int)ptask.a, sbase = (int)ptask.b;
+        const int nsub = (int)A.tasks[parent].a, sbase = (int)A.tasks[parent].b;
         if (old_done + 1 != nsub) break;  // not the last one: take the next ticket
         __threadfence();
         int succ = -1;
@@ -314,13 +320,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_search(SearchArgs A)
         if (lane == 0) A.out_cnt[parent] = found;
         WAVE_SYNC();
         ti = parent;
-        task = ptask;
         sub = false;
         b = (long long)A.B << upto;
       }
       if (final_pass) break;
       if (found >= A.k) {  // doubling loop ends here (postfilter_vamana.h:161-172); final re-search?
-        long long fb = b * ((task.flags & 2) ? 1 : A.mult);
+        long long fb = b * ((A.tasks[ti].flags & 2) ? 1 : A.mult);
         if (fb > A.max_beam) fb = A.max_beam;
         if (fb <= b) break;
         if (fb <= cap) {

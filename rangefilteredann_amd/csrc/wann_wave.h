@@ -290,7 +290,7 @@ __device__ __forceinline__ void wave_touch_rows(const IndexView &ix, const int32
 
 // Distances of `cnt` rows whose (sorted-order) row numbers sit in ids_lds[0..cnt): afterwards lane
 // s < cnt holds the distance of row s.  scratch_lds: 64 floats.
-template <int METRIC>
+template <int METRIC, bool TWO_ROWS = true>
 __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32_t *ids_lds,
                                                 float *scratch_lds, const float *qv, int cnt,
                                                 int64_t row_off) {
@@ -326,7 +326,7 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
   } else {
     const int D8 = (ix.d + 7) >> 3;
     const int h = lane & 1;
-    if (D8 == 16 || D8 == 12) {  // d = 128 / 96: one round trip for up to 64 candidates
+    if (TWO_ROWS && (D8 == 16 || D8 == 12)) {  // d = 128 / 96: one round trip for up to 64 candidates
       const int s0 = lane >> 1, s1 = 32 + (lane >> 1);
       const bool act0 = s0 < cnt, act1 = s1 < cnt;
       const int id0 = act0 ? ids_lds[s0] : 0, id1 = act1 ? ids_lds[s1] : 0;
@@ -351,6 +351,8 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
         const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
         float dist;
         switch (D8) {  // wave-uniform
+          case 16: dist = l2_pair_ct<16>(prow, qv, h, act); break;  // d = 128 (TWO_ROWS = false)
+          case 12: dist = l2_pair_ct<12>(prow, qv, h, act); break;  // d = 96
           case 13: dist = l2_pair_ct<13>(prow, qv, h, act); break;  // d = 100
           case 8: dist = l2_pair_ct<8>(prow, qv, h, act); break;    // d = 64
           default: dist = l2_pair<16>(prow, qv, D8, h, act); break;
@@ -889,8 +891,12 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       const u64 dlast = D ? rdlane64(dk, D - 1) : 0ull;
       cutoff = funkey((uint32_t)(((mlk | 1ull) > (dlast | 1ull) ? mlk : dlast) >> 32));
     }
+    // (the delta list waits in the merge scratch meanwhile: the scoring routine keeps two whole rows per lane pair in
+    // flight and needs every register)
+    L.cand_key[lane] = dk;
     const float dist = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, nt, row_off);
     const int cid = (lane < nt) ? L.cand_id[lane] : 0;
+    dk = L.cand_key[lane];
     WAVE_SYNC();
     const bool pass = (lane < nt) && (dist < cutoff);
     const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);

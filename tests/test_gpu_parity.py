@@ -43,6 +43,52 @@ def test_raw_beam_search_matches_oracle(oracle, wa, gpu, metric, gen, d, beam):
         assert int(cmps[i]) == dc, (i, cmps[i], dc)
 
 
+def _hash64_2(x):
+    """parlay::hash64_2 (parlay/utilities.h:145-150)"""
+    m = (1 << 64) - 1
+    x &= m
+    x = ((x ^ (x >> 30)) * 0xbf58476d1ce4e5b9) & m
+    x = ((x ^ (x >> 27)) * 0x94d049bb133111eb) & m
+    return x ^ (x >> 31)
+
+
+@pytest.mark.parametrize("env", [{}, {"WANN_FORCE_GENERAL": "1"}, {"WANN_OLD_GENERAL": "1"}, {"WANN_RAW_BIG_LDS": "1"},
+                                 {"WANN_RAW_BIG_LDS": "1", "WANN_FORCE_GENERAL": "1"}], ids=lambda e: "+".join(sorted(e)) or "default")
+@pytest.mark.parametrize("metric,gen,d", [(0, sift_like, 128), (1, unit_mixture, 100)])
+def test_raw_beam_search_core_variants(oracle, wa, gpu, monkeypatch, env, metric, gen, d):
+    """Every beam-search core (register-resident, second-generation general with the exact seen set / delta list / tagged
+    filter, first-generation general, one- and four-wave kernels) against the oracle: ids, distances, hops, dist_cmps.
+    The graph has rows that list the start node twice with a node of the same filter slot in between -- the one case in
+    which the reference's multiset union keeps two copies of an entry."""
+    n, nq, R, L = 6000, 64, 32, 64
+    g = gen(n, d, 12)
+    X, Q = g(n), g(nq)
+    Xp = oracle.pad_rows(X)
+    start, sn = 300, 5000
+    rows = oracle.vamana_build(Xp, d, metric, start, sn, R, L, 1.0).copy()
+    # (0, b, 0) with hash(b) = hash(0) in the 2^10-slot filter of the small beams: ~5 such b among 5000 nodes
+    same = [b for b in range(1, sn) if (_hash64_2(b) ^ _hash64_2(0)) & 1023 == 0]
+    assert same
+    rng = np.random.default_rng(3)
+    for r in rng.choice(sn, 300, replace=False):
+        b = same[int(r) % len(same)]
+        deg = max(int(rows[r, 0]), 3)
+        rows[r, 0] = deg
+        rows[r, 1:4] = (0, b, 0)
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    qids = np.arange(nq, dtype=np.int64) + 10**6
+    for beam in (16, 40, 100, 160, 300, 1000, 2500):
+        ids, dists, sizes, hops, cmps = wa.raw_beam_search(metric, X, rows, start, Q, qids, beam)
+        for i in range(nq):
+            oi, od, vi, vd, dc = oracle.beam_search(rows, Xp, d, metric, start, Q[i], int(qids[i]), beam)
+            m = int(sizes[i])
+            assert m == len(oi), (beam, i, m, len(oi))
+            assert np.array_equal(ids[i, :m], oi), (beam, i)
+            assert np.array_equal(dists[i, :m], od), (beam, i)
+            assert int(hops[i]) == len(vi) and int(cmps[i]) == dc, (beam, i, hops[i], len(vi), cmps[i], dc)
+
+
 def test_raw_beam_search_limits(oracle, wa, gpu):
     n, d, nq = 1500, 32, 40
     g = sift_like(n, d, 5)
@@ -333,8 +379,8 @@ def test_scheduling_variants_return_identical_rows(wa, gpu, tmp_path, monkeypatc
     labels = distinct_labels(n, 6)
     idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(32, 100, 1.0, ""))
     base = {}
-    for env in ({}, {"WANN_NO_SPEC": "1"}, {"WANN_FORCE_GENERAL": "1"}, {"WANN_NO_SPEC": "1", "WANN_FORCE_GENERAL": "1"}):
-        for k_ in ("WANN_NO_SPEC", "WANN_FORCE_GENERAL"):
+    for env in ({}, {"WANN_NO_SPEC": "1"}, {"WANN_FORCE_GENERAL": "1"}, {"WANN_NO_SPEC": "1", "WANN_FORCE_GENERAL": "1"}, {"WANN_OLD_GENERAL": "1"}):
+        for k_ in ("WANN_NO_SPEC", "WANN_FORCE_GENERAL", "WANN_OLD_GENERAL"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
@@ -364,8 +410,8 @@ def test_big_workgroup_levels_return_identical_rows(wa, gpu, monkeypatch):
     idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, ""))
     W = windows(labels, nq, -9, seed=5)
     base = {}
-    for env in ({}, {"WANN_NO_BIG": "1"}, {"WANN_NO_SPEC": "1"}):
-        for k_ in ("WANN_NO_SPEC", "WANN_NO_BIG"):
+    for env in ({}, {"WANN_NO_BIG": "1"}, {"WANN_NO_SPEC": "1"}, {"WANN_OLD_GENERAL": "1"}):
+        for k_ in ("WANN_NO_SPEC", "WANN_NO_BIG", "WANN_OLD_GENERAL"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)

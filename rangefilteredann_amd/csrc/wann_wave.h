@@ -921,8 +921,10 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       if (pmask && M + D + popc64(pmask) > B) load_chunk();
       for (u64 mm = pmask; mm; mm &= mm - 1) {
         const u64 k = rdlane64(key, ctz64(mm));
-        if (M + D == B) {  // full: the largest entry leaves
+        if (M + D == B) {  // full: the largest entry leaves -- unless that is the candidate itself (an earlier candidate of this
+                           // hop has lowered the last entry below it: the truncation of beamSearch.h:157 would drop it)
           const u64 dlast = D ? rdlane64(dk, D - 1) : 0ull;
+          if ((k | 1ull) > (mlk | 1ull) && (k | 1ull) > (dlast | 1ull)) continue;
           if ((mlk | 1ull) > (dlast | 1ull)) {
             M--;
             if (tbase - M >= 64) load_chunk();

@@ -317,7 +317,8 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   const int wpb = big_lds ? 1 : kWavesPerBlock;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
   int pool = kSearchPoolBytes;
-  if (big_lds) pool = (int)std::min<int64_t>(std::max<int64_t>(cap_bytes, kSearchPoolBytes), 150 * 1024 - common);
+  // (one-wave kernel: + the clash-detection scratch and the prefetch helper's mailbox beside the largest beam)
+  if (big_lds) pool = (int)std::min<int64_t>(std::max<int64_t>(cap_bytes + 4096 + 64, kSearchPoolBytes), 150 * 1024 - common);
   rc.pool_bytes = pool;
   const int per_block = (common + pool) * wpb;
   if (per_block > 160 * 1024) throw std::runtime_error("beam-search LDS footprint exceeds 160 KiB");
@@ -613,6 +614,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0);
       big_lds = rc.big_lds;
       a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
+      a.helper = (big_lds && !getenv("WANN_NO_HELPER")) ? 1 : 0;
       a.B = (int32_t)first_beam;
       a.cap_inkernel = (int32_t)cap;
       a.pool_bytes = rc.pool_bytes;
@@ -631,6 +633,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         with_big = true;
         const int common = search_lds_bytes_per_wave(I.view.stride, 0);
         big = a;
+        big.helper = getenv("WANN_NO_HELPER") ? 0 : 1;
         big.cap_inkernel = with_big_cap;
         big.pool_bytes = (common + kSearchPoolBytes) * kWavesPerBlock - common;
         big.big_list = W.list_big.p;
@@ -1193,6 +1196,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
     DevBuf<uint32_t> g_seen;
     int64_t layout = -1;
     sa.old_general = old_general ? 1 : 0;
+    sa.helper = (rc.big_lds && !getenv("WANN_NO_HELPER")) ? 1 : 0;
     if (rc.table_bits) {
       const int64_t seen_words = ((subset_n + 127) / 128) * 4;
       ensure_filter_scratch(g_table, g_epoch, g_seen, layout, rc.slots, rc.table_bits, seen_words, nullptr);

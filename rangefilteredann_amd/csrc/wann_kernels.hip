@@ -54,20 +54,30 @@ __device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:
 // continuations handed over by ordinary waves until every ordinary ticket is done.  Two kernels rather than
 // two modes of one: the mode logic cost the ordinary kernel 20 VGPRs (it needs all 256 of two waves per SIMD).
 template <int METRIC, bool BIG>
-__global__ __launch_bounds__(BIG ? 64 : 64 * kWavesPerBlock, BIG ? 1 : 2) void k_search(SearchArgs A) {  // (!BIG: two waves per SIMD, at most 256 VGPRs)
+__global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void k_search(SearchArgs A) {  // (!BIG: two waves per SIMD, at most 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
-  const int slot = blockIdx.x * (blockDim.x >> 6) + wib;  // 4 waves per workgroup, 1 for the large-beam launches
+  // four searching waves per workgroup; the one-wave kernel has ONE searching wave (plus, with A.helper, its prefetch helper)
+  const int slot = BIG ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6) + wib);
   const int per_wave = wave_lds_common_bytes(ix.stride) + A.pool_bytes;
-  unsigned char *base = smem + (size_t)wib * per_wave;
+  unsigned char *base = smem + (BIG ? 0 : (size_t)wib * per_wave);
+  // the helper's mailbox takes the last bytes of the pool
+  PrefetchBox *const box = (BIG && A.helper) ? reinterpret_cast<PrefetchBox *>(base + per_wave - (int)sizeof(PrefetchBox)) : nullptr;
+  if (BIG && A.helper) {
+    if (wib == 0 && lane == 0) {
+      volatile int32_t *vb = reinterpret_cast<volatile int32_t *>(box);
+      for (int j = 0; j < (int)(sizeof(PrefetchBox) / 4); j++) vb[j] = 0;
+    }
+    __syncthreads();  // (the only workgroup barrier of the kernel: the mailbox is initialised before the helper polls it)
+  }
   u64 *gbeam = A.g_beam ? A.g_beam + (size_t)slot * A.g_beam_cap : nullptr;
   int32_t *const gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
   const int heavy = A.heavy_count ? *A.heavy_count : 0;
   const int mid_end = heavy + (A.mid_count ? *A.mid_count : 0);
   const int total = mid_end + *A.list_count;  // ordinary tickets
-  const int pool_bytes = A.pool_bytes, cap = A.cap_inkernel;
+  const int pool_bytes = A.pool_bytes - ((BIG && A.helper) ? (int)sizeof(PrefetchBox) : 0), cap = A.cap_inkernel;
   // BIG: the first npollers workgroups only serve continuations, so that one starts as soon as it is handed over
   bool polling = BIG && A.big_list && (int)blockIdx.x < A.npollers;
   if (BIG && polling && A.big_count[0] + A.big_count[1] == 0) return;  // (pollers only in batches that have big levels at all)
@@ -78,6 +88,11 @@ __global__ __launch_bounds__(BIG ? 64 : 64 * kWavesPerBlock, BIG ? 1 : 2) void k
     if (items > 0 && (int)blockIdx.x < min(items + A.npollers, (int)gridDim.x / 2)) return;
   }
 
+  if (BIG && A.helper && wib == 1) {  // the prefetch helper wave of this workgroup's search wave
+    prefetch_helper(ix, A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr,
+                    A.g_seen ? A.g_seen + (size_t)slot * A.g_seen_words : nullptr, A.degree_limit, box);
+    return;
+  }
   for (;;) {
     int ti;
     bool dyn = false;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(BIG ? 64 : 64 * kWavesPerBlock, BIG ? 1 : 2) void k
           mini_mask = 127u;
         }
         wave_beam_search_big<METRIC>(ix, part, L, gtable, tag, A.g_seen + (size_t)slot * A.g_seen_words, B, bits, qid, A.limit,
-                                     A.degree_limit, mini, mini_mask, m, nvis, ncmp, A.prof);
+                                     A.degree_limit, mini, mini_mask, m, nvis, ncmp, A.prof, BIG ? box : nullptr, A.tasks[ti].part);
       } else if (BIG) {
         // First-generation general cores: only in the one-wave-per-workgroup kernel (512 registers per wave), which
         // serves the companion launch, the follow-up launches and the test / dev switches.
@@ -364,6 +379,7 @@ __global__ __launch_bounds__(BIG ? 64 : 64 * kWavesPerBlock, BIG ? 1 : 2) void k
       if (lane == 0) __hip_atomic_fetch_add(A.done_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if (BIG && box && lane == 0) *reinterpret_cast<volatile int32_t *>(box) = -1;  // the helper wave leaves too
 }
 
 // --------------------------------------------------------------------------------------------
@@ -947,7 +963,7 @@ int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream) {
   if (cfg.blocks <= 0) return 0;
   const int wpb = cfg.waves_per_block > 0 ? cfg.waves_per_block : kWavesPerBlock;
   size_t lds = (size_t)search_lds_bytes_per_wave(a.ix.stride, a.pool_bytes) * wpb;
-  dim3 grid(cfg.blocks), block(64 * wpb);
+  dim3 grid(cfg.blocks), block(64 * wpb * ((cfg.big && a.helper) ? 2 : 1));  // (+ the prefetch helper wave)
   hipStream_t s = (hipStream_t)stream;
   if (cfg.big) return a.ix.metric == 1 ? launch_search_t<1, true>(a, grid, block, lds, s) : launch_search_t<0, true>(a, grid, block, lds, s);
   return a.ix.metric == 1 ? launch_search_t<1, false>(a, grid, block, lds, s) : launch_search_t<0, false>(a, grid, block, lds, s);

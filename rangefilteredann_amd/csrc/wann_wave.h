@@ -713,17 +713,167 @@ __device__ __forceinline__ u64 wave_shr1(u64 v) {  // lane i receives lane i-1's
   return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
+// --------------------------------------------------------------------------------------------
+// Prefetch helper wave (one-wave-per-search kernel only).  A long search is one chain of dependent hops, each of
+// which is three dependent memory round trips (adjacency row -> filter / seen-set probes -> vectors).  The search
+// wave publishes, after every hop, the nodes it is likely to visit next (the first unvisited entries of its beam);
+// a second wave of the same workgroup walks exactly that chain for those nodes AHEAD of the search -- row, then
+// the filter slots and seen-set words of the row's neighbours, then the vector lines of the neighbours that are
+// not scored yet -- and throws the data away: its only effect is that the search wave's own loads hit the L2.
+// No data flows back, so the helper cannot change a result; a wrong or late prediction costs a cache miss.
+// --------------------------------------------------------------------------------------------
+struct PrefetchBox {   // LDS mailbox, written by the search wave
+  int32_t gen;         // < 0: the kernel is ending; 0: no search is running; > 0: generation of the running search
+  int32_t seq;         // bumped after every update of pred[]
+  int32_t part;        // partition of the running search
+  int32_t bits;        // its filter size (log2)
+  int32_t pred[6];     // nodes likely to be visited next (-1: none)
+  int32_t pad[6];
+};
+
+__device__ __forceinline__ void prefetch_publish(PrefetchBox *box, const u64 *mb, int M, int pm, u64 dk, int D) {
+  const int lane = lane_id();
+  // first three unvisited entries of the LDS beam at or after pm, first two unvisited entries of the delta list
+  const int x = pm + lane;
+  const u64 v = x < M ? mb[x] : 1ull;
+  u64 um = ballot64(!(v & 1ull));
+  u64 dm = ballot64(lane < D && !(dk & 1ull));
+  int pr[5];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    pr[j] = -1;
+    if (um) {
+      pr[j] = (int)(rdlane((int)(uint32_t)v, ctz64(um)) >> 1) & 0x7fffffff;
+      um &= um - 1;
+    }
+  }
+#pragma unroll
+  for (int j = 3; j < 5; j++) {
+    pr[j] = -1;
+    if (dm) {
+      pr[j] = (int)(rdlane((int)(uint32_t)dk, ctz64(dm)) >> 1) & 0x7fffffff;
+      dm &= dm - 1;
+    }
+  }
+  if (lane == 0) {
+    volatile int32_t *vp = box->pred;
+#pragma unroll
+    for (int j = 0; j < 5; j++) vp[j] = pr[j];
+    *(volatile int32_t *)&box->seq = box->seq + 1;
+  }
+}
+
+__device__ __forceinline__ void prefetch_helper(const IndexView &ix, int32_t *gtable, const uint32_t *gseen, int degree_limit,
+                                                PrefetchBox *box) {
+  const int lane = lane_id();
+  constexpr int K = 8;
+  int rid = -1, rst = 0;  // lane e < K: node of ring slot e, its stage (0 free, 1 row requested, 2 probes issued, 3 done)
+  int rrow[K];
+  uint32_t rE[K];
+#pragma unroll
+  for (int e = 0; e < K; e++) {
+    rrow[e] = -1;
+    rE[e] = 0;
+  }
+  int my_gen = 0, my_seq = -1, head = 0;
+  int64_t row_base = 0, row_off = 0;
+  uint32_t tmask = 0;
+  const int lpr = (ix.stride * 4 + 127) >> 7;  // 128-B lines per vector row
+  for (;;) {
+    const int gen = *(volatile int32_t *)&box->gen;
+    if (gen < 0) return;
+    if (gen == 0) {
+      my_gen = 0;
+      __builtin_amdgcn_s_sleep(16);
+      continue;
+    }
+    if (gen != my_gen) {  // a new search: forget the ring
+      my_gen = gen;
+      my_seq = -1;
+      rid = -1;
+      rst = 0;
+      head = 0;
+      const PartDesc pd = ix.parts[*(volatile int32_t *)&box->part];
+      row_base = pd.row_base;
+      row_off = pd.start;
+      tmask = (1u << *(volatile int32_t *)&box->bits) - 1u;
+    }
+    bool issued = false;
+    // ---- what was requested in the previous round has arrived (the registers are read below): next stage
+#pragma unroll
+    for (int e = 0; e < K; e++) {
+      const int st = rdlane(rst, e);
+      if (st == 1) {  // row -> filter slots and seen-set words of its neighbours
+        const int a = rrow[e];
+        const bool valid = (a >= 0) && (lane < degree_limit);
+        uint32_t w = ~0u;
+        if (valid) {
+          const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
+          (void)*reinterpret_cast<const volatile int32_t *>(gtable + loc);
+          w = gseen[a >> 5];
+        }
+        rE[e] = w;
+        if (lane == e) rst = 2;
+        issued = true;
+      } else if (st == 2) {  // seen-set words -> vector lines of the neighbours that are not scored yet
+        const int a = rrow[e];
+        const bool want = (a >= 0) && (lane < degree_limit) && !((rE[e] >> (a & 31)) & 1u);
+        if (want) {
+          const float *row = ix.points + (row_off + a) * (int64_t)ix.stride;
+          for (int l = 0; l < lpr; l++) (void)*reinterpret_cast<const volatile int *>(row + l * 32);
+        }
+        if (lane == e) rst = 3;
+        issued = true;
+      }
+    }
+    // ---- new predictions: request their rows
+    const int seq = *(volatile int32_t *)&box->seq;
+    if (seq != my_seq) {
+      my_seq = seq;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const int pnode = *(volatile int32_t *)&box->pred[j];
+        if (pnode < 0 || ballot64(lane < K && rid == pnode)) continue;
+        const int slot = head & (K - 1);
+        head++;
+        if (lane == slot) {
+          rid = pnode;
+          rst = 1;
+        }
+        int a = -1;
+        if (lane < ix.rs) a = ix.graph[(row_base + pnode) * (int64_t)ix.rs + lane];
+#pragma unroll
+        for (int e = 0; e < K; e++)
+          if (slot == e) rrow[e] = a;
+        issued = true;
+      }
+    }
+    if (!issued) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 template <int METRIC>
 __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const PartDesc &part, const WaveLds &L,
                                                      int32_t *gtable, uint32_t tag, uint32_t *gseen, int B, int bits,
                                                      int64_t qid, int64_t limit, int degree_limit, int32_t *mini,
                                                      uint32_t mini_mask, int &m_out, long long &nvis_out,
-                                                     long long &ncmp_out, unsigned long long *prof = nullptr) {
+                                                     long long &ncmp_out, unsigned long long *prof = nullptr,
+                                                     PrefetchBox *box = nullptr, int part_index = 0) {
   prof = WANN_PROF_PTR(prof);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = part.start;
   u64 *const mb = L.lbeam;
+  if (box && lane == 0) {  // a new search for the prefetch helper wave
+    volatile int32_t *vb = reinterpret_cast<volatile int32_t *>(box);
+    vb[2] = part_index;
+    vb[3] = bits;
+    for (int j = 0; j < 6; j++) vb[4 + j] = -1;
+    vb[1] = 0;
+    const int g = vb[10] + 1;  // pad[0]: the last generation used (generations never repeat within a launch)
+    vb[10] = g;
+    vb[0] = g;
+  }
   {  // exact seen set of this search: empty
     int4 *sv = reinterpret_cast<int4 *>(gseen);
     const int n16 = (part.n + 127) >> 7;
@@ -948,9 +1098,11 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
         D++;
       }
     }
+    if (box) prefetch_publish(box, mb, M, pm, dk, D);
     WANN_PHASE(3);  // insertion
   }
 #undef WANN_PHASE
+  if (box && lane == 0) *reinterpret_cast<volatile int32_t *>(box) = 0;  // (the next search picks the next generation)
   flush();
   if (prof && lane == 0)
     for (int i = 0; i < 5; i++) atomicAdd(&prof[i], acc[i]);

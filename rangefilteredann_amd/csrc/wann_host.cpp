@@ -1225,6 +1225,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
       HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof h, hipMemcpyDeviceToHost));
       fprintf(stderr, "[wann phases] beam=%ld nq=%ld cycles: row %llu filter %llu dist %llu merge %llu next %llu | loop %llu passing %llu\n", (long)beam,
               (long)nq, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+      fprintf(stderr, "[wann waits] cycles: row load %llu, filter + seen probes %llu, scoring routine %llu\n", h[5], h[6], h[7]);
     }
     HIP_CHECK(hipMemcpy(out_ids, d_rid.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_dists, d_rd.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));

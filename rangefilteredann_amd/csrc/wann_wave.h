@@ -731,38 +731,6 @@ struct PrefetchBox {   // LDS mailbox, written by the search wave
   int32_t pad[6];
 };
 
-__device__ __forceinline__ void prefetch_publish(PrefetchBox *box, const u64 *mb, int M, int pm, u64 dk, int D) {
-  const int lane = lane_id();
-  // first three unvisited entries of the LDS beam at or after pm, first two unvisited entries of the delta list
-  const int x = pm + lane;
-  const u64 v = x < M ? mb[x] : 1ull;
-  u64 um = ballot64(!(v & 1ull));
-  u64 dm = ballot64(lane < D && !(dk & 1ull));
-  int pr[5];
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    pr[j] = -1;
-    if (um) {
-      pr[j] = (int)(rdlane((int)(uint32_t)v, ctz64(um)) >> 1) & 0x7fffffff;
-      um &= um - 1;
-    }
-  }
-#pragma unroll
-  for (int j = 3; j < 5; j++) {
-    pr[j] = -1;
-    if (dm) {
-      pr[j] = (int)(rdlane((int)(uint32_t)dk, ctz64(dm)) >> 1) & 0x7fffffff;
-      dm &= dm - 1;
-    }
-  }
-  if (lane == 0) {
-    volatile int32_t *vp = box->pred;
-#pragma unroll
-    for (int j = 0; j < 5; j++) vp[j] = pr[j];
-    *(volatile int32_t *)&box->seq = box->seq + 1;
-  }
-}
-
 __device__ __forceinline__ void prefetch_helper(const IndexView &ix, int32_t *gtable, const uint32_t *gseen, int degree_limit,
                                                 PrefetchBox *box) {
   const int lane = lane_id();
@@ -831,7 +799,7 @@ __device__ __forceinline__ void prefetch_helper(const IndexView &ix, int32_t *gt
     if (seq != my_seq) {
       my_seq = seq;
 #pragma unroll
-      for (int j = 0; j < 5; j++) {
+      for (int j = 0; j < 3; j++) {
         const int pnode = *(volatile int32_t *)&box->pred[j];
         if (pnode < 0 || ballot64(lane < K && rid == pnode)) continue;
         const int slot = head & (K - 1);
@@ -850,6 +818,57 @@ __device__ __forceinline__ void prefetch_helper(const IndexView &ix, int32_t *gt
     }
     if (!issued) __builtin_amdgcn_s_sleep(8);
   }
+}
+
+// Distances of a row's own entries: every lane flagged `take` receives the distance of its entry `a`.  The flagged
+// entries are packed onto lane pairs through the cross-lane network (ds_permute: the r-th flagged lane pushes its id to
+// the pair r mod 32), a pair scores ONE row per pass (passes of 32; the second pass only while more than 32 entries
+// are new, i.e. in a search's first hops), and the owner pulls the result back (ds_bpermute).  No trip of ids or
+// results through LDS memory (wave_distances costs four LDS round trips per hop) and half the registers of the two-rows-
+// per-pair routine; same arithmetic, same evaluation order.
+__device__ __forceinline__ int pair_swap_i(int v) {  // the value of the other lane of my pair
+  return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+}
+
+template <int METRIC>
+__device__ __forceinline__ float wave_distances_own(const IndexView &ix, int a, bool take, const float *qv, int64_t row_off) {
+  const int lane = lane_id();
+  const int h = lane & 1;
+  const u64 tm = ballot64(take);
+  const int nt = popc64(tm);
+  const int r = popc64(tm & lanemask_lt());
+  float mine = 0.f;
+  for (int base = 0; base < nt; base += 32) {
+    // the r-th flagged lane -> even lane of pair r - base (the others push to lane 1, which nobody reads)
+    const bool now = take && r >= base && r < base + 32;
+    const int got = __builtin_amdgcn_ds_permute(now ? ((r - base) << 3) : 4, a);
+    const int ev = h ? pair_swap_i(got) : got;  // both lanes of the pair
+    const int s = lane >> 1;
+    const int id = (base + s < nt) ? ev : 0;  // idle pairs score node 0: no branches
+    const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
+    float dd;
+    if (METRIC == 1) {
+      const int np = (((ix.d + 3) >> 2) + 1) >> 1;
+      switch (np) {  // wave-uniform
+        case 12: dd = mips_pair_ct<12>(prow, qv, ix.d, h); break;
+        case 13: dd = mips_pair_ct<13>(prow, qv, ix.d, h); break;
+        default: dd = mips_pair(prow, qv, ix.d, h); break;
+      }
+    } else {
+      const int D8 = (ix.d + 7) >> 3;
+      switch (D8) {  // wave-uniform
+        case 16: dd = l2_pair_ct<16>(prow, qv, h, true); break;
+        case 12: dd = l2_pair_ct<12>(prow, qv, h, true); break;
+        case 13: dd = l2_pair_ct<13>(prow, qv, h, true); break;
+        case 8: dd = l2_pair_ct<8>(prow, qv, h, true); break;
+        default: dd = l2_pair<16>(prow, qv, D8, h, true); break;
+      }
+    }
+    // the result sits in the odd lane of the pair (in both for the inner product): the owner pulls it
+    const float back = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((((r - base) << 1) | 1) << 2, __builtin_bit_cast(int, dd)));
+    if (now) mine = back;
+  }
+  return mine;
 }
 
 template <int METRIC>
@@ -902,17 +921,37 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     if (M > 0) v = mb[M - 1];  // uniform address: an LDS broadcast
     mlk = rdlane64(v, 0);
   };
-  auto rescan = [&](int s) {  // pm = first unvisited entry at or after s
+  // pm = first unvisited entry at or after s; with a helper wave the next unvisited entries of the same chunk are
+  // published as the nodes to prefetch
+  auto rescan = [&](int s, bool publish) {
     pm = M;
     pmk = ~0ull;
     while (s < M) {
       const int x = s + lane;
       const u64 v = x < M ? mb[x] : 1ull;
-      const u64 um = ballot64(!(v & 1ull));
+      u64 um = ballot64(!(v & 1ull));
       if (um) {
         const int i = ctz64(um);
         pm = s + i;
         pmk = rdlane64(v, i);
+        if (publish && box) {
+          int pr[3];
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            pr[j] = -1;
+            if (um) {
+              pr[j] = (int)((uint32_t)rdlane((int)(uint32_t)v, ctz64(um)) >> 1);
+              um &= um - 1;
+            }
+          }
+          if (lane == 0) {
+            volatile int32_t *vb = reinterpret_cast<volatile int32_t *>(box);
+            vb[4] = pr[0];
+            vb[5] = pr[1];
+            vb[6] = pr[2];
+            vb[1] = vb[1] + 1;
+          }
+        }
         break;
       }
       s += 64;
@@ -925,10 +964,10 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     D = 0;
     dk = ~0ull;
     load_last();
-    rescan(pm < p0 ? pm : p0);
+    rescan(pm < p0 ? pm : p0, false);
   };
 
-  unsigned long long tp = 0, acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tp = 0, acc[6] = {0, 0, 0, 0, 0, 0}, pacc[3] = {0, 0, 0}, tw0 = 0;
 #define WANN_PHASE(i)                                       \
   do {                                                      \
     if (prof) {                                             \
@@ -961,10 +1000,18 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     nvis++;
     // ---- adjacency row, coalesced (graph.h:198); -1 = unused slot
     int a = -1;
+    if (prof) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      tw0 = __builtin_readcyclecounter();
+    }
     if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
+    if (prof) {  // pure load latency of the row
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pacc[0] += __builtin_readcyclecounter() - tw0;
+    }
     if (!from_delta) {  // (LDS only: overlaps the row's flight)
       WAVE_SYNC();
-      rescan(pm + 1);
+      rescan(pm + 1, true);
     }
     const bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
     if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -975,9 +1022,17 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     const int tagged = (int)(tag | (uint32_t)a);
     int old = -1;
     uint32_t sw = 0;
+    if (prof) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      tw0 = __builtin_readcyclecounter();
+    }
     if (valid) {
       old = gtable[loc];
       sw = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (prof) {  // pure load latency of the two probes
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pacc[1] += __builtin_readcyclecounter() - tw0;
     }
     // exact test "two valid lanes of the row share a filter slot": every lane tags its slot of a small LDS hash with
     // its lane number; a lane that lost its slot compares filter slots with the winner, and the few lanes whose
@@ -1028,10 +1083,6 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     const bool fresh = kept && !((sw >> (a & 31)) & 1u);
     const bool take = twice ? kept : fresh;  // what is computed
     if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 tmask64 = ballot64(take);
-    const int nt = popc64(tmask64);
-    if (take) L.cand_id[popc64(tmask64 & lanemask_lt())] = a;
-    WAVE_SYNC();
     WANN_PHASE(1);  // seen-filter
 
     if (twice) flush();  // the exact multiset union below works on the whole beam
@@ -1041,71 +1092,67 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       const u64 dlast = D ? rdlane64(dk, D - 1) : 0ull;
       cutoff = funkey((uint32_t)(((mlk | 1ull) > (dlast | 1ull) ? mlk : dlast) >> 32));
     }
+    if (prof) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      tw0 = __builtin_readcyclecounter();
+    }
     // (the delta list waits in the merge scratch meanwhile: the scoring routine keeps two whole rows per lane pair in
     // flight and needs every register)
     L.cand_key[lane] = dk;
-    const float dist = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, nt, row_off);
-    const int cid = (lane < nt) ? L.cand_id[lane] : 0;
+    const float dist = wave_distances_own<METRIC>(ix, a, take, L.qv, row_off);
     dk = L.cand_key[lane];
-    WAVE_SYNC();
-    const bool pass = (lane < nt) && (dist < cutoff);
-    const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);
+    if (prof) pacc[2] += __builtin_readcyclecounter() - tw0;  // the scoring routine alone
+    const bool pass = take && (dist < cutoff);
+    const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
     WANN_PHASE(2);  // vector fetch + distances
 
     // ---- union + truncate (beamSearch.h:148-157)
+    const u64 pmask = ballot64(pass);
     if (twice) {
       int p0;
       M = wave_merge(mb, M, B, pass, key, L.cand_key, &p0);
       load_last();
-      rescan(pm < p0 ? pm : p0);
-    } else {
-      // the last entries of the LDS beam (they leave one by one while the beam is full): lane j holds mb[tbase - 1 - j]
-      const u64 pmask = ballot64(pass);
-      int tbase = 0;
-      u64 tailv = 0;
-      auto load_chunk = [&]() {
-        tbase = M;
-        const int x = M - 1 - lane;
-        tailv = x >= 0 ? mb[x] : 0ull;
-      };
-      if (pmask && M + D + popc64(pmask) > B) load_chunk();
-      for (u64 mm = pmask; mm; mm &= mm - 1) {
+      rescan(pm < p0 ? pm : p0, false);
+    } else if (pmask) {
+      const int c = popc64(pmask);
+      if (D + c > 64) flush();
+      for (u64 mm = pmask; mm; mm &= mm - 1) {  // into the delta list, one lane shift each
         const u64 k = rdlane64(key, ctz64(mm));
-        if (M + D == B) {  // full: the largest entry leaves -- unless that is the candidate itself (an earlier candidate of this
-                           // hop has lowered the last entry below it: the truncation of beamSearch.h:157 would drop it)
-          const u64 dlast = D ? rdlane64(dk, D - 1) : 0ull;
-          if ((k | 1ull) > (mlk | 1ull) && (k | 1ull) > (dlast | 1ull)) continue;
-          if ((mlk | 1ull) > (dlast | 1ull)) {
-            M--;
-            if (tbase - M >= 64) load_chunk();
-            mlk = M > 0 ? rdlane64(tailv, tbase - M) : 0ull;
-            if (pm >= M) {
-              pm = M;
-              pmk = ~0ull;
-            }
-          } else {
-            D--;
-            if (lane == D) dk = ~0ull;
-          }
-        }
-        if (D == 64) {
-          flush();
-          load_chunk();
-        }
         const int pos = popc64(ballot64(lane < D && (dk | 1ull) < (k | 1ull)));
         const u64 up = wave_shr1(dk);
         dk = lane < pos ? dk : (lane == pos ? k : up);
         D++;
       }
+      const int excess = M + D - B;
+      if (excess > 0) {
+        // truncate to B: the `excess` largest entries of (LDS beam, delta list) leave.  Both are sorted; delta entry
+        // i-from-the-end is among them iff fewer than excess - i beam entries exceed it, i.e. iff the beam entry
+        // excess - i - 1 from the end (if there is one) is smaller.
+        const int ai = D - 1 - lane;
+        const u64 av = __shfl(dk, ai >= 0 ? ai : 0);  // delta, from the end
+        const int bi = M - excess + lane;
+        const u64 bv = (lane < excess && bi >= 0) ? mb[bi] : 0ull;
+        const bool leaves = lane < excess && ai >= 0 && (bi < 0 || (bv | 1ull) < (av | 1ull));
+        const int t = popc64(ballot64(leaves));
+        D -= t;
+        if (lane >= D) dk = ~0ull;
+        M -= excess - t;
+        load_last();
+        if (pm >= M) {
+          pm = M;
+          pmk = ~0ull;
+        }
+      }
     }
-    if (box) prefetch_publish(box, mb, M, pm, dk, D);
     WANN_PHASE(3);  // insertion
   }
 #undef WANN_PHASE
   if (box && lane == 0) *reinterpret_cast<volatile int32_t *>(box) = 0;  // (the next search picks the next generation)
   flush();
-  if (prof && lane == 0)
+  if (prof && lane == 0) {
     for (int i = 0; i < 5; i++) atomicAdd(&prof[i], acc[i]);
+    for (int i = 0; i < 3; i++) atomicAdd(&prof[5 + i], pacc[i]);
+  }
   m_out = M;
   nvis_out = nvis;
   ncmp_out = ncmp;

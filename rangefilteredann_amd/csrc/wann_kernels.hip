@@ -72,7 +72,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void 
     }
     __syncthreads();  // (the only workgroup barrier of the kernel: the mailbox is initialised before the helper polls it)
   }
-  u64 *gbeam = A.g_beam ? A.g_beam + (size_t)slot * A.g_beam_cap : nullptr;
+  u64 *gbeam = (BIG && A.g_beam) ? A.g_beam + (size_t)slot * A.g_beam_cap : nullptr;  // (beams outside the LDS: one-wave kernel only)
   int32_t *const gtable = A.g_table ? A.g_table + ((size_t)slot << A.g_table_bits) : nullptr;
   const int heavy = A.heavy_count ? *A.heavy_count : 0;
   const int mid_end = heavy + (A.mid_count ? *A.mid_count : 0);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void 
         nvis = ncmp = 0;
         if (lane == 0) atomicAdd(&A.ctr->unsupported, 1ull);
       }
-      auto beam_ld = [&](int i) -> u64 { return beam_lds ? L.lbeam[i] : gbeam[i]; };
+      auto beam_ld = [&](int i) -> u64 { return (!BIG || beam_lds) ? L.lbeam[i] : gbeam[i]; };
 #ifdef WANN_TASK_TRACE
       if (A.trace && lane == 0) {
         long long *rec = A.trace + 1 + 4 * atomicAdd((unsigned long long *)A.trace, 1ull);

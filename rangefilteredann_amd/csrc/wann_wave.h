@@ -826,8 +826,11 @@ __device__ __forceinline__ void prefetch_helper(const IndexView &ix, int32_t *gt
 // are new, i.e. in a search's first hops), and the owner pulls the result back (ds_bpermute).  No trip of ids or
 // results through LDS memory (wave_distances costs four LDS round trips per hop) and half the registers of the two-rows-
 // per-pair routine; same arithmetic, same evaluation order.
-__device__ __forceinline__ int pair_swap_i(int v) {  // the value of the other lane of my pair
-  return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+// Both lanes of a pair receive the even lane's value: ONE DPP move whose bank mask enables the odd lanes only.  (Not
+// `odd ? swap(v) : v`: hipcc turns that select into a branch and runs the DPP move with the even lanes disabled -- a
+// DPP read of a disabled lane returns 0.)
+__device__ __forceinline__ int pair_even_value(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xA /* banks 1 and 3 */, false);
 }
 
 template <int METRIC>
@@ -842,7 +845,7 @@ __device__ __forceinline__ float wave_distances_own(const IndexView &ix, int a, 
     // the r-th flagged lane -> even lane of pair r - base (the others push to lane 1, which nobody reads)
     const bool now = take && r >= base && r < base + 32;
     const int got = __builtin_amdgcn_ds_permute(now ? ((r - base) << 3) : 4, a);
-    const int ev = h ? pair_swap_i(got) : got;  // both lanes of the pair
+    const int ev = pair_even_value(got);  // both lanes of the pair
     const int s = lane >> 1;
     const int id = (base + s < nt) ? ev : 0;  // idle pairs score node 0: no branches
     const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;

@@ -826,11 +826,13 @@ __device__ __forceinline__ void prefetch_helper(const IndexView &ix, int32_t *gt
 // are new, i.e. in a search's first hops), and the owner pulls the result back (ds_bpermute).  No trip of ids or
 // results through LDS memory (wave_distances costs four LDS round trips per hop) and half the registers of the two-rows-
 // per-pair routine; same arithmetic, same evaluation order.
-// Both lanes of a pair receive the even lane's value: ONE DPP move whose bank mask enables the odd lanes only.  (Not
-// `odd ? swap(v) : v`: hipcc turns that select into a branch and runs the DPP move with the even lanes disabled -- a
-// DPP read of a disabled lane returns 0.)
+// Both lanes of a pair receive the even lane's value.  The DPP move is pinned (empty asm) in the uniform block it is
+// written in: hipcc otherwise turns `odd ? swap(v) : v` into a branch and runs the move with the even lanes disabled --
+// and a DPP read of a disabled lane returns 0.
 __device__ __forceinline__ int pair_even_value(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xA /* banks 1 and 3 */, false);
+  int sw = __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+  asm volatile("" : "+v"(sw));
+  return (lane_id() & 1) ? sw : v;
 }
 
 template <int METRIC>

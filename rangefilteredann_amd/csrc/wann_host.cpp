@@ -61,7 +61,7 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
@@ -508,6 +508,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.mid_list = W.list_mid.p;
   ra.mid_count = W.ints.p + I_MID_COUNT;
   ra.heavy_ratio = getenv("WANN_HEAVY_RATIO") ? atoi(getenv("WANN_HEAVY_RATIO")) : 8;
+  ra.risk_count = W.ints.p + I_RISK;
   ra.brute_list = W.list_brute.p;
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
   ra.spec = spec ? 1 : 0;
@@ -707,14 +708,17 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.next_list = W.list_b.p;
     sa.next_count = W.ints.p + I_NEXT0;
     sa.final_count = W.ints.p + I_FINAL0;
-    launch(sa, b0, cap1, graph_n, false, big_n > 0 ? big_cap : 0);
+    // the companion launch also runs when there are no levels beyond the cap yet but heavy tasks that may have to
+    // double beyond it: its pollers then serve those continuations at once instead of a follow-up launch
+    const bool may_continue = W.h_ints[I_RISK] > 0 && use_pollers;
+    launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue) ? big_cap : 0);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
     // continuations handed to the companion launch's pollers that nobody served (the runtime serialised the two
     // launches, or a poller gave up): entries >= 0 of dyn_list.  They join the follow-up launch (next_beam holds
     // the beam each one continues with), so the batch completes with the same rows.
-    if (big_n > 0 && use_pollers && W.h_ints[I_DYN_COUNT] > 0) {
+    if (use_pollers && W.h_ints[I_DYN_COUNT] > 0) {
       const int dyn_n = W.h_ints[I_DYN_COUNT];
       std::vector<int32_t> dl((size_t)dyn_n), unserved;
       HIP_CHECK(hipMemcpyAsync(dl.data(), W.list_big.p + 2 * (size_t)W.big_stride, (size_t)dyn_n * 4, hipMemcpyDeviceToHost, st));

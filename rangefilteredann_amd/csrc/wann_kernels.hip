@@ -80,12 +80,12 @@ __global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void 
   const int pool_bytes = A.pool_bytes - ((BIG && A.helper) ? (int)sizeof(PrefetchBox) : 0), cap = A.cap_inkernel;
   // BIG: the first npollers workgroups only serve continuations, so that one starts as soon as it is handed over
   bool polling = BIG && A.big_list && (int)blockIdx.x < A.npollers;
-  if (BIG && polling && A.big_count[0] + A.big_count[1] == 0) return;  // (pollers only in batches that have big levels at all)
+
   // ordinary launch with a companion: as many ordinary workgroups as there are big items (+ pollers) leave at once, so that
   // the companion's workgroups (launched first, but the LDS of every CU is fully booked by this launch) find room
   if (!BIG && A.yield_for_big) {
     const int items = A.big_count[0] + A.big_count[1];
-    if (items > 0 && (int)blockIdx.x < min(items + A.npollers, (int)gridDim.x / 2)) return;
+    if ((int)blockIdx.x < min(items + A.npollers, (int)gridDim.x / 2)) return;
   }
 
   if (BIG && A.helper && wib == 1) {  // the prefetch helper wave of this workgroup's search wave
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void 
       if (nb > cap) {
         if (lane == 0) {
           if (A.next_beam) A.next_beam[ti] = (int32_t)nb;
-          if (!BIG && A.npollers > 0 && nb <= A.big_cap && A.big_count[0] + A.big_count[1] > 0) {  // to a poller of the companion launch
+          if (!BIG && A.npollers > 0 && nb <= A.big_cap) {  // to a poller of the companion launch
             __threadfence();
             const int d = atomicAdd(A.dyn_count, 1);
             __hip_atomic_store(A.dyn_list + d, ti, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -547,6 +547,7 @@ struct Emitter {
       // a first beam that expects fewer than 4k in-window entries fails now and then: such a task starts before the
       // bulk, so that its second, longer search is not what the launch ends with
       if (t.mode == T_GRAPH && (uint64_t)A.beam * w < 4ull * (uint64_t)A.k * (uint64_t)pd.n) t.flags |= 8;
+      if (t.mode == T_GRAPH && w > 0 && 4ull * (uint64_t)A.k * (uint64_t)pd.n >= (uint64_t)A.cap_inkernel * w) atomicAdd(A.risk_count, 1);
       if (t.mode == T_GRAPH && w > 0 && (uint64_t)pd.n / w >= (uint64_t)A.heavy_ratio) {
         t.flags |= 1;
         if (A.spec && n < A.maxt) {

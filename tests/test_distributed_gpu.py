@@ -35,7 +35,7 @@ def test_sharded_batch_search_on_nccl_world_1(gpu):
 def test_bench_under_the_launcher_with_one_rank(gpu, tmp_path):
     """small shapes; the RCCL all-gather sits inside the timed step"""
     cmd = _torchrun(os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--points", "30000", "--nq", "500",
-                    "--fractions", "headline", "--no-cpu-baseline", "--cache", str(tmp_path))
+                    "--fractions", "headline", "--configs", "none", "--no-cpu-baseline", "--cache", str(tmp_path))
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=_env())
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

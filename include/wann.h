@@ -161,6 +161,24 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d,
                          float *out_dists /* nq x beam */, int32_t *out_sizes /* nq */,
                          int64_t *out_hops /* nq */, int64_t *out_dist_cmps /* nq */, int device);
 
+/* Unfiltered VamanaIndex<T,Point> (ParlayANN/python/vamana_index.cpp:42-76, bound at python_bindings.cpp:92-109): a graph
+ * index opened from a point file (uint32 n, uint32 d, n*d elements of dtype: point_range.h:63-93) and a graph file
+ * (graph.h:126-196: the format of the graph cache).  batch_search = beam_search from node 0 with
+ * QueryParams(knn, beam_width, 1.35, n, max_degree) -- including the k / cut step of beamSearch.h:159-167, which only this
+ * path takes -- and the first knn entries of the final beam (a shorter beam is padded with id 2^32-1, FLT_MAX; the reference
+ * reads past it).  queries: host (nq,d) of the index's dtype. */
+typedef struct wann_vamana wann_vamana;
+wann_vamana *wann_vamana_open(int metric, int dtype, const char *data_path, const char *graph_path, int device);
+void wann_vamana_close(wann_vamana *index);
+int64_t wann_vamana_num_points(const wann_vamana *index);
+int64_t wann_vamana_dim(const wann_vamana *index);
+int wann_vamana_batch_search(wann_vamana *index, const void *queries, int64_t nq, int64_t knn, int64_t beam_width,
+                             uint32_t *ids, float *dists);
+/* build_vamana_index (ParlayANN/python/builder.cpp:33-59, bound at python_bindings.cpp:93-95): point file -> graph file,
+ * built on the GPU with the reference's insertion order */
+int wann_vamana_build_file(int metric, int dtype, const char *data_path, const char *graph_out_path, int64_t max_degree,
+                           int64_t limit, double alpha, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,8 @@ struct SearchArgs {
   uint32_t *g_seen;
   int64_t g_seen_words;
   int32_t old_general;          // dev / test: the first-generation general core (wave_beam_search) instead
+  int32_t cut_k;                // raw mode, unfiltered VamanaIndex queries: QueryParams::k and ::cut of beamSearch.h:159-167
+  double cut;                   //   (0: no cut step -- the post-filter path never takes it)
   int32_t helper;               // one-wave kernel: a second wave per workgroup prefetches ahead of the search (prefetch_helper)
   unsigned long long *g_beam;   // per wave slot beam, g_beam_cap entries each (or null)
   int64_t g_beam_cap;

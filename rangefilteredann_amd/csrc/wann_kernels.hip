@@ -184,7 +184,13 @@ __global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void 
         wave_beam_search_small<METRIC, 1>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
       else if (small_ok && B <= 128)
         wave_beam_search_small<METRIC, 2>(ix, part, L, B, bits, qid, A.limit, A.degree_limit, m, nvis, ncmp, A.prof);
-      else if (beam_lds && A.g_seen && !(BIG && A.old_general)) {
+      else if (!BIG && beam_lds && gtable) {
+        // Four-wave kernel, beams 129 .. cap_inkernel: the first-generation general core.  (Measured: the second-
+        // generation core below wins from beams of about 2 000 entries on -- the one-wave kernel's range -- and loses
+        // a tenth per hop at beams of a few hundred, where many candidates pass per hop.)
+        wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
+                                                     nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask);
+      } else if (BIG && beam_lds && A.g_seen && !A.old_general) {
         // Second-generation general core.  Tagged filter entries: this search takes the slot's next epoch; on
         // wrap-around (or after a search that stored plain ids) the slot's whole region is zeroed.  Partitions of
         // more than 2^24 nodes use plain ids and clear what they use.
@@ -211,20 +217,21 @@ __global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void 
           mini_mask = 127u;
         }
         wave_beam_search_big<METRIC>(ix, part, L, gtable, tag, A.g_seen + (size_t)slot * A.g_seen_words, B, bits, qid, A.limit,
-                                     A.degree_limit, mini, mini_mask, m, nvis, ncmp, A.prof, BIG ? box : nullptr, A.tasks[ti].part);
+                                     A.degree_limit, mini, mini_mask, m, nvis, ncmp, A.prof, box, A.tasks[ti].part);
       } else if (BIG) {
         // First-generation general cores: only in the one-wave-per-workgroup kernel (512 registers per wave), which
         // serves the companion launch, the follow-up launches and the test / dev switches.
         if (A.g_epoch && lane == 0) A.g_epoch[slot] = 254;  // plain ids go into the table: the next tagged search clears it
+        uint32_t *const vset = (A.cut_k > 0 && A.g_seen) ? A.g_seen + (size_t)slot * A.g_seen_words : nullptr;
         if (table_lds)
           wave_beam_search<METRIC, true, true, false>(ix, part, L, nullptr, nullptr, B, bits, qid, A.limit, A.degree_limit,
-                                                      nullptr, 0, m, nvis, ncmp, A.prof);
+                                                      nullptr, 0, m, nvis, ncmp, A.prof, nullptr, 0, A.cut_k, A.cut, vset);
         else if (beam_lds)
           wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
-                                                       nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask);
+                                                       nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask, A.cut_k, A.cut, vset);
         else
           wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
-                                                        nullptr, 0, m, nvis, ncmp, A.prof);
+                                                        nullptr, 0, m, nvis, ncmp, A.prof, nullptr, 0, A.cut_k, A.cut, vset);
       } else {
         // (the host never gives the four-wave kernel a beam that needs one of those: see config_for)
         m = 0;

@@ -537,7 +537,8 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
                                                  int64_t limit, int degree_limit, u64 *vis, int vis_cap,
                                                  int &m_out, long long &nvis_out, long long &ncmp_out,
                                                  unsigned long long *prof = nullptr, int32_t *mini = nullptr,
-                                                 uint32_t mini_mask = 0) {
+                                                 uint32_t mini_mask = 0, int cut_k = 0, double cut = 0.0,
+                                                 uint32_t *vset = nullptr) {
   prof = WANN_PROF_PTR(prof);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
@@ -548,6 +549,16 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
   } else {
     int4 *gt = reinterpret_cast<int4 *>(gtable);
     for (int i = lane; i < (1 << (bits - 2)); i += 64) gt[i] = make_int4(-1, -1, -1, -1);
+  }
+  // With the cut step a VISITED entry can leave the beam and be admitted again later (the beam is no longer always full,
+  // so the cutoff is not monotone): the reference keeps its visited list (beamSearch.h:114-116,175-178), here the exact
+  // set of visited nodes is a bitmap and a re-admitted node gets its visited bit back.  (Without the cut an evicted node
+  // can never return and the bit in the beam entry is all that is needed.)
+  if (vset) {
+    int4 *sv = reinterpret_cast<int4 *>(vset);
+    const int n16 = (part.n + 127) >> 7;
+    for (int i = lane; i < n16; i += 64) sv[i] = make_int4(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // frontier = {start node 0} (beamSearch.h:80-82)
   if (lane == 0) L.cand_id[0] = 0;
@@ -582,6 +593,7 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     if (lane == 0) {
       beam_st(p, curkey | 1ull);
       if (COLLECT && nvis < vis_cap) vis[nvis] = curkey & ~1ull;
+      if (vset) __hip_atomic_fetch_or(vset + (cur >> 5), 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     nvis++;
 
@@ -651,13 +663,31 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     int cid = (lane < nk) ? L.cand_id[lane] : 0;
     WAVE_SYNC();
     const bool pass = (lane < nk) && (dist < cutoff);
-    const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);
+    u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)cid << 1);
+    if (vset && pass && ((__hip_atomic_load(vset + (cid >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (cid & 31)) & 1u)) key |= 1ull;
     WANN_PHASE(2);  // vector fetch + distances
 
     // ---- sort + set_union + truncate (beamSearch.h:148-157)
     int p0;
     if (BEAM_LDS) m = wave_merge(L.lbeam, m, B, pass, key, L.cand_key, &p0);
     else m = wave_merge(gbeam, m, B, pass, key, L.cand_key, &p0);
+    // ---- beamSearch.h:159-167: with a k (unfiltered VamanaIndex queries) and a metric distance, entries beyond
+    //      cut * (distance of entry k) leave: upper_bound of (id 0, that distance) under (dist, id) order
+    if (METRIC == 0 && cut_k > 0 && m > cut_k) {
+      const float thr = (float)(cut * (double)funkey((uint32_t)(beam_ld(cut_k) >> 32)));
+      int keep = 0;
+      for (int s0 = 0; s0 < m; s0 += 64) {
+        const int x = s0 + lane;
+        const u64 ev = x < m ? beam_ld(x) : ~0ull;
+        const float dv = funkey((uint32_t)(ev >> 32));
+        const bool stay = x < m && (dv < thr || (dv == thr && ((uint32_t)ev >> 1) == 0u));
+        const u64 sm = ballot64(stay);
+        keep += popc64(sm);
+        if (sm != ~0ull) break;  // (sorted: the entries that stay are a prefix)
+      }
+      m = keep;
+      if (p0 > m) p0 = m;
+    }
     WANN_PHASE(3);  // sort + merge
 
     // ---- next = first beam entry not yet visited (beamSearch.h:175-178)

@@ -12,6 +12,8 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <vector>
+#include <cstdio>
 
 #include "../../include/wann.h"
 
@@ -265,6 +267,113 @@ static void add_variant(py::module_ &m, const std::string &agnostic) {
   }
 }
 
+// ---- unfiltered VamanaIndex<T,Point> (ParlayANN/python/vamana_index.cpp:42-76, python_bindings.cpp:92-109) -------------
+// The reference's constructor is VamanaIndex(data_path, index_path, num_points, dimensions) but its binding names the
+// arguments "index_path", "data_path" in that order: the FIRST argument (keyword index_path) is the point file and the
+// second (keyword data_path) the graph file.  Kept as is: positional and keyword calls behave like the reference's.
+template <int METRIC, int DTYPE>
+struct VamanaIndexT {
+  wann_vamana *h = nullptr;
+  VamanaIndexT(const std::string &first_called_index_path, const std::string &second_called_data_path, size_t num_points, size_t dimensions) {
+    h = wann_vamana_open(METRIC, DTYPE, first_called_index_path.c_str(), second_called_data_path.c_str(), 0);
+    if (!h) raise_last("VamanaIndex");
+    // (the reference asserts these; assert() is compiled out of its release build)
+    (void)num_points;
+    (void)dimensions;
+  }
+  ~VamanaIndexT() { wann_vamana_close(h); }
+  VamanaIndexT(const VamanaIndexT &) = delete;
+  NeighborsAndDistances search_raw(const void *q, uint64_t nq, uint64_t knn, uint64_t beam) {
+    py::array_t<unsigned int> ids({(size_t)nq, (size_t)knn});
+    py::array_t<float> dists({(size_t)nq, (size_t)knn});
+    if (wann_vamana_batch_search(h, q, (int64_t)nq, (int64_t)knn, (int64_t)beam, ids.mutable_data(), dists.mutable_data()))
+      raise_last("batch_search");
+    return {std::move(ids), std::move(dists)};
+  }
+  NeighborsAndDistances batch_search(py::array queries, uint64_t nq, uint64_t knn, uint64_t beam) {
+    const int64_t d = wann_vamana_dim(h);
+    if (DTYPE == WANN_DTYPE_F32) {
+      FArray q = FArray::ensure(queries);
+      if (!q || q.ndim() != 2 || q.shape(1) != d || (uint64_t)q.shape(0) < nq) throw std::runtime_error("queries must be a (num_queries, dimensions) array");
+      return search_raw(q.data(), nq, knn, beam);
+    }
+    if (DTYPE == WANN_DTYPE_U8) {
+      auto q = py::array_t<uint8_t, py::array::c_style | py::array::forcecast>::ensure(queries);
+      if (!q || q.ndim() != 2 || q.shape(1) != d || (uint64_t)q.shape(0) < nq) throw std::runtime_error("queries must be a (num_queries, dimensions) array");
+      return search_raw(q.data(), nq, knn, beam);
+    }
+    auto q = py::array_t<int8_t, py::array::c_style | py::array::forcecast>::ensure(queries);
+    if (!q || q.ndim() != 2 || q.shape(1) != d || (uint64_t)q.shape(0) < nq) throw std::runtime_error("queries must be a (num_queries, dimensions) array");
+    return search_raw(q.data(), nq, knn, beam);
+  }
+  // queries from a point file (uint32 n, uint32 d, data)
+  NeighborsAndDistances batch_search_from_string(const std::string &path, uint64_t nq, uint64_t knn, uint64_t beam) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open query file " + path);
+    uint32_t head[2] = {0, 0};
+    const size_t esz = DTYPE == WANN_DTYPE_F32 ? 4 : 1;
+    std::vector<unsigned char> raw;
+    bool ok = fread(head, 4, 2, f) == 2 && (int64_t)head[1] == wann_vamana_dim(h) && head[0] >= nq;
+    if (ok) {
+      raw.resize((size_t)nq * head[1] * esz);
+      ok = raw.empty() || fread(raw.data(), 1, raw.size(), f) == raw.size();
+    }
+    fclose(f);
+    if (!ok) throw std::runtime_error("query file does not hold num_queries points of the index's dimension: " + path);
+    return search_raw(raw.data(), nq, knn, beam);
+  }
+  // ground truth file: int32 n, int32 width, n*width uint32 ids, n*width float distances (types.h:33-74); recall counts
+  // every ground-truth point tied with the k-th distance (vamana_index.cpp:104-132) and is printed like the reference prints it
+  double check_recall(const std::string &gfile, py::array_t<unsigned int, py::array::c_style | py::array::forcecast> neighbors, int k) {
+    FILE *f = fopen(gfile.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open ground truth file " + gfile);
+    int32_t head[2] = {0, 0};
+    if (fread(head, 4, 2, f) != 2 || head[0] < 0 || head[1] < k) {
+      fclose(f);
+      throw std::runtime_error("bad ground truth file " + gfile);
+    }
+    const size_t n = (size_t)head[0], w = (size_t)head[1];
+    std::vector<uint32_t> ids(n * w);
+    std::vector<float> ds(n * w);
+    const bool ok = fread(ids.data(), 4, n * w, f) == n * w && fread(ds.data(), 4, n * w, f) == n * w;
+    fclose(f);
+    if (!ok) throw std::runtime_error("truncated ground truth file " + gfile);
+    if (neighbors.ndim() != 2 || (size_t)neighbors.shape(0) < n || neighbors.shape(1) < k) throw std::runtime_error("neighbors must be (n, >= k)");
+    long correct = 0;
+    for (size_t i = 0; i < n; i++) {
+      size_t cnt = (size_t)k;
+      while (cnt < w && ds[i * w + cnt] == ds[i * w + k - 1]) cnt++;
+      for (size_t l = 0; l < cnt; l++)
+        for (int j = 0; j < k; j++)
+          if (neighbors.at(i, j) == ids[i * w + l]) {
+            correct++;
+            break;
+          }
+    }
+    const double recall = (float)correct / (float)((size_t)k * n);
+    py::print("Recall:", recall);
+    return recall;
+  }
+};
+
+template <int METRIC, int DTYPE>
+static void add_vamana(py::module_ &m, const std::string &lower, const std::string &cls) {
+  m.def(("build_vamana_" + lower + "_index").c_str(),
+        [](const std::string &distance_metric, const std::string &data_file_path, const std::string &index_output_path, uint32_t graph_degree,
+           uint32_t beam_width, float alpha) {
+          (void)distance_metric;  // (unused by the reference too: the variant fixes the metric)
+          if (wann_vamana_build_file(METRIC, DTYPE, data_file_path.c_str(), index_output_path.c_str(), graph_degree, beam_width, alpha, 0))
+            raise_last("build_vamana_index");
+        },
+        "distance_metric"_a, "data_file_path"_a, "index_output_path"_a, "graph_degree"_a, "beam_width"_a, "alpha"_a);
+  using V = VamanaIndexT<METRIC, DTYPE>;
+  py::class_<V>(m, cls.c_str())
+      .def(py::init<const std::string &, const std::string &, size_t, size_t>(), "index_path"_a, "data_path"_a, "num_points"_a, "dimensions"_a)
+      .def("batch_search", &V::batch_search, "queries"_a, "num_queries"_a, "knn"_a, "beam_width"_a)
+      .def("batch_search_from_string", &V::batch_search_from_string, "queries"_a, "num_queries"_a, "knn"_a, "beam_width"_a)
+      .def("check_recall", &V::check_recall, "gFile"_a, "neighbors"_a, "k"_a);
+}
+
 }  // namespace wannpy
 
 PYBIND11_MODULE(_window_ann, m) {
@@ -291,6 +400,14 @@ PYBIND11_MODULE(_window_ann, m) {
   add_variant<WANN_METRIC_MIPS, WANN_DTYPE_U8>(m, "UInt8Mips");
   add_variant<WANN_METRIC_L2, WANN_DTYPE_I8>(m, "Int8Euclidian");
   add_variant<WANN_METRIC_MIPS, WANN_DTYPE_I8>(m, "Int8Mips");
+
+  // python_bindings.cpp:67-86: builder and index names of the unfiltered Vamana variants
+  add_vamana<WANN_METRIC_L2, WANN_DTYPE_F32>(m, "float_euclidian", "VamanaFloatEuclidianIndex");
+  add_vamana<WANN_METRIC_MIPS, WANN_DTYPE_F32>(m, "float_mips", "VamanaFloatMipsIndex");
+  add_vamana<WANN_METRIC_L2, WANN_DTYPE_U8>(m, "uint8_euclidian", "VamanaUInt8EuclidianIndex");
+  add_vamana<WANN_METRIC_MIPS, WANN_DTYPE_U8>(m, "uint8_mips", "VamanaUInt8MipsIndex");
+  add_vamana<WANN_METRIC_L2, WANN_DTYPE_I8>(m, "int8_euclidian", "VamanaInt8EuclidianIndex");
+  add_vamana<WANN_METRIC_MIPS, WANN_DTYPE_I8>(m, "int8_mips", "VamanaInt8MipsIndex");
 
   // experiments/wrapper.py:245 spells the uint8 classes "Uint8" while the reference registers "UInt8"
   // (python_bindings.cpp:74-79), so its uint8 constructors raise AttributeError there; both spellings resolve here.

@@ -84,7 +84,7 @@ struct RouteArgs {
   int32_t *heavy_list, *heavy_count;  // graph tasks expected to need several doublings
   int32_t *mid_list, *mid_count;      // graph tasks whose first beam may well fail (expected in-window entries < 4k): served second
   int32_t heavy_ratio;                // partition size / window size at or above which a task is heavy
-  int32_t *risk_count;                // graph tasks whose predicted beam (k * partition / window) reaches a quarter of cap_inkernel:
+  int32_t *risk_count;                // graph tasks whose predicted beam (k * partition / window) reaches half of cap_inkernel:
                                       // they may have to double beyond it (the host then starts the continuation pollers)
   int32_t *brute_list, *brute_count;
   // speculative doubling: a heavy task spawns one sub-task per beam level b0 << r, r = 0 .. nsub-1,

@@ -54,7 +54,7 @@ __device__ __forceinline__ int hash_bits_dev(long long beam) {  // beamSearch.h:
 // continuations handed over by ordinary waves until every ordinary ticket is done.  Two kernels rather than
 // two modes of one: the mode logic cost the ordinary kernel 20 VGPRs (it needs all 256 of two waves per SIMD).
 template <int METRIC, bool BIG>
-__global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void k_search(SearchArgs A) {  // (!BIG: two waves per SIMD, at most 256 VGPRs)
+__global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock) void k_search(SearchArgs A) {  // (!BIG must stay within 256 VGPRs: two waves per SIMD; an explicit occupancy hint made the schedule 5 % slower)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id();
@@ -223,15 +223,18 @@ __global__ __launch_bounds__(BIG ? 128 : 64 * kWavesPerBlock, BIG ? 1 : 2) void 
         // serves the companion launch, the follow-up launches and the test / dev switches.
         if (A.g_epoch && lane == 0) A.g_epoch[slot] = 254;  // plain ids go into the table: the next tagged search clears it
         uint32_t *const vset = (A.cut_k > 0 && A.g_seen) ? A.g_seen + (size_t)slot * A.g_seen_words : nullptr;
-        if (table_lds)
+        if (A.cut_k > 0 && beam_lds)  // unfiltered VamanaIndex queries: the k / cut step (global filter: the host forces one)
+          wave_beam_search<METRIC, false, true, false, true>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
+                                                             nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask, A.cut_k, A.cut, vset);
+        else if (table_lds)
           wave_beam_search<METRIC, true, true, false>(ix, part, L, nullptr, nullptr, B, bits, qid, A.limit, A.degree_limit,
-                                                      nullptr, 0, m, nvis, ncmp, A.prof, nullptr, 0, A.cut_k, A.cut, vset);
+                                                      nullptr, 0, m, nvis, ncmp, A.prof);
         else if (beam_lds)
           wave_beam_search<METRIC, false, true, false>(ix, part, L, nullptr, gtable, B, bits, qid, A.limit, A.degree_limit,
-                                                       nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask, A.cut_k, A.cut, vset);
+                                                       nullptr, 0, m, nvis, ncmp, A.prof, mini, mini_mask);
         else
           wave_beam_search<METRIC, false, false, false>(ix, part, L, gbeam, gtable, B, bits, qid, A.limit, A.degree_limit,
-                                                        nullptr, 0, m, nvis, ncmp, A.prof, nullptr, 0, A.cut_k, A.cut, vset);
+                                                        nullptr, 0, m, nvis, ncmp, A.prof);
       } else {
         // (the host never gives the four-wave kernel a beam that needs one of those: see config_for)
         m = 0;
@@ -554,7 +557,7 @@ struct Emitter {
       // a first beam that expects fewer than 4k in-window entries fails now and then: such a task starts before the
       // bulk, so that its second, longer search is not what the launch ends with
       if (t.mode == T_GRAPH && (uint64_t)A.beam * w < 4ull * (uint64_t)A.k * (uint64_t)pd.n) t.flags |= 8;
-      if (t.mode == T_GRAPH && w > 0 && 4ull * (uint64_t)A.k * (uint64_t)pd.n >= (uint64_t)A.cap_inkernel * w) atomicAdd(A.risk_count, 1);
+      if (t.mode == T_GRAPH && w > 0 && 2ull * (uint64_t)A.k * (uint64_t)pd.n >= (uint64_t)A.cap_inkernel * w) atomicAdd(A.risk_count, 1);
       if (t.mode == T_GRAPH && w > 0 && (uint64_t)pd.n / w >= (uint64_t)A.heavy_ratio) {
         t.flags |= 1;
         if (A.spec && n < A.maxt) {

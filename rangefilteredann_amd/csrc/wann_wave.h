@@ -531,7 +531,7 @@ __device__ __forceinline__ WaveLds carve_wave_lds(unsigned char *base, int strid
   return L;
 }
 
-template <int METRIC, bool TABLE_LDS, bool BEAM_LDS, bool COLLECT>
+template <int METRIC, bool TABLE_LDS, bool BEAM_LDS, bool COLLECT, bool CUT = false>
 __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const PartDesc &part, const WaveLds &L,
                                                  u64 *gbeam, int32_t *gtable, int B, int bits, int64_t qid,
                                                  int64_t limit, int degree_limit, u64 *vis, int vis_cap,
@@ -540,6 +540,10 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
                                                  uint32_t mini_mask = 0, int cut_k = 0, double cut = 0.0,
                                                  uint32_t *vset = nullptr) {
   prof = WANN_PROF_PTR(prof);
+  if (!CUT) {  // (compile-time: the post-filter path never takes the cut step and keeps no scalar state for it)
+    cut_k = 0;
+    vset = nullptr;
+  }
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = part.start;

@@ -123,3 +123,17 @@ def test_engine_kernels_use_no_scratch(wa, tmp_path):
     assert len(seen) >= 15, seen
     bad = {k: v for k, v in seen.items() if v != 0}
     assert not bad, f"kernels with a scratch segment: {bad}"
+
+
+def test_four_wave_search_kernels_fit_two_waves_per_simd(wa):
+    """k_search<., false> runs four waves per workgroup, two workgroups per CU: each wave may use at most 256 VGPRs."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "kernel_resources.py"),
+                          "k_search"], capture_output=True, text=True, timeout=300)
+    if out.returncode != 0 or not out.stdout.strip():
+        pytest.skip("ROCm llvm tools not present")
+    lean = [l for l in out.stdout.splitlines() if "Lb0E" in l]
+    assert len(lean) == 2
+    for l in lean:
+        assert int(l.split("vgpr")[1].split()[0]) <= 256, l

@@ -1,7 +1,7 @@
 """Dev tool: VGPR / SGPR / scratch / LDS of every gfx950 kernel inside libwann.so (reads the code objects' notes)."""
 import os, re, subprocess, sys, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = os.path.join(REPO, "rangefilteredann_amd", "libwann.so")
+lib = os.environ.get("WANN_LIB", os.path.join(REPO, "rangefilteredann_amd", "libwann.so"))
 llvm = "/opt/rocm/lib/llvm/bin"
 tmp = tempfile.mkdtemp()
 fat = os.path.join(tmp, "fat.bin")

@@ -40,7 +40,8 @@ enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP =
 
 /* distance: Euclidian_Point (squared L2, euclidian_point.h:62-75) / Mips_Point (-<q,p>, mips_point.h:60-76) */
 enum { WANN_METRIC_L2 = 0, WANN_METRIC_MIPS = 1 };
-/* element type of points/queries (python_bindings.cpp:232-237); the device path is float32 */
+/* element type of points/queries (python_bindings.cpp:232-237): float32 rows, or uint8 / int8 BYTE rows scored with
+ * v_dot4 into exact int32 sums (euclidian_point.h:44-60, mips_point.h:44-58), any dimension */
 enum { WANN_DTYPE_F32 = 0, WANN_DTYPE_U8 = 1, WANN_DTYPE_I8 = 2 };
 /* index classes */
 enum {
@@ -97,8 +98,7 @@ const char *wann_last_error(void);
 int wann_device_count(void);
 
 /* Build (or load from the graph cache) an index and make it resident in the HBM of `device`.
- * points: (n,d) row-major of `dtype` (uint8 / int8 sets: d <= 258, or 1024 for int8 inner products -- the
- * range in which the reference's int32 arithmetic is reproduced exactly; device rows are fp32); labels: (n) float32.  cutoff / split_factor /
+ * points: (n,d) row-major of `dtype` (uint8 / int8 sets stay bytes on the device); labels: (n) float32.  cutoff / split_factor /
  * shift_factor as in the reference constructors (ignored by kinds that have none).
  * build_threads <= 0: PARLAY_NUM_THREADS if set, else all host cores. */
 wann_index *wann_index_create(int kind, int metric, int dtype, const void *points, int64_t n,

@@ -27,6 +27,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 L2, MIPS = 0, 1
+INTEGER = 2  # | : integer-valued rows of a uint8 / int8 point set (int32 distances, restate.h ORC_INTEGER)
 PREFILTER, POSTFILTER, TREE_PREFILTER, TREE_VAMANA, SUPER = range(5)
 
 
@@ -208,15 +209,12 @@ class _Index:
 def _mk(kind, metric, tree_method, elem=None):
     """elem = np.uint8 / np.int8: the reference's byte variants (euclidian_point.h:44-60, mips_point.h:44-58
     accumulate in int32 and cast to float).  Points and queries are cast to the element type as pybind's
-    py::array_t<T> does, then restated with integer-valued fp32 rows -- exact while d * max_term < 2^24."""
+    py::array_t<T> does; the rows then hold the integer values and the restatement accumulates in int32 too
+    (metric | INTEGER), exact for any dimension."""
     def cast(a):
         if elem is None:
             return a
-        a = np.asarray(a).astype(elem)
-        bound = 128 * 128 if (elem is np.int8 and metric == MIPS) else 255 * 255
-        if a.shape[-1] * bound >= 1 << 24:
-            raise RuntimeError("byte variants are restated exactly up to 258 dimensions only")
-        return a.astype(np.float32)
+        return np.asarray(a).astype(elem).astype(np.float32)
 
     class K(_Index):
         KIND = kind
@@ -224,7 +222,8 @@ def _mk(kind, metric, tree_method, elem=None):
         def __init__(self, points, filter_values=None, cutoff=1000, split_factor=2,
                      shift_factor=0.5, build_params=None, filters=None, threads=None):
             lab = filter_values if filter_values is not None else filters
-            super().__init__(metric, cast(points), lab, cutoff, split_factor, shift_factor, build_params, threads)
+            super().__init__(metric | (INTEGER if elem is not None else 0), cast(points), lab, cutoff, split_factor, shift_factor,
+                             build_params, threads)
 
         if tree_method:
             def batch_search(self, queries, filters, num_queries, query_method, query_params):

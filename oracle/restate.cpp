@@ -196,7 +196,23 @@ float dist_mips(const float *p, const float *q, uint32_t d) {
   return -r;
 }
 
+// uint8 / int8 point sets (metric | ORC_INTEGER): the rows hold the integer element values and the distance is the
+// reference's int32 accumulation cast to float (euclidian_point.h:44-60, mips_point.h:44-58), exact for any dimension.
+float dist_integer(bool mips, const float *p, const float *q, uint32_t d) {
+  int32_t r = 0;
+  if (mips) {
+    for (uint32_t i = 0; i < d; i++) r += (int32_t)q[i] * (int32_t)p[i];
+    return -((float)r);
+  }
+  for (uint32_t i = 0; i < d; i++) {
+    const int32_t t = (int32_t)p[i] - (int32_t)q[i];
+    r += t * t;
+  }
+  return (float)r;
+}
+
 inline float distance(int metric, const float *p, const float *q, uint32_t d) {
+  if (metric & ORC_INTEGER) return dist_integer((metric & 1) == ORC_MIPS, p, q, d);
   return metric == ORC_MIPS ? dist_mips(p, q, d) : dist_l2(p, q, d);
 }
 
@@ -309,7 +325,7 @@ void beam_search(const SearchArgs &A, SearchOut &out) {
   bool have_next = true;
   pid next = frontier[0];
   int64_t num_visited = 0;
-  const bool metric_is_metric = (A.metric == ORC_L2);  // euclidian_point.h:71, mips_point.h:72
+  const bool metric_is_metric = ((A.metric & 1) == ORC_L2);  // euclidian_point.h:71, mips_point.h:72
 
   while (have_next && num_visited < A.limit) {  // :108
     pid cur = next;

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-enum { ORC_L2 = 0, ORC_MIPS = 1 };
+enum { ORC_L2 = 0, ORC_MIPS = 1, ORC_INTEGER = 2 /* | : integer-valued rows of a uint8 / int8 point set, int32 distances */ };
 
 /* index kinds (python_bindings/python_bindings.cpp:111-157) */
 enum {

@@ -175,8 +175,28 @@ static inline float mips_ref_order(const float *p, const float *q, int d) {
   return -r;
 }
 
+// uint8 / int8 rows (d bytes behind the float pointer): exact int32 sums cast to float, like the reference's
+// (euclidian_point.h:44-60, mips_point.h:44-58) and like the device's v_dot4 routines
+template <typename T>
+static float byte_distance(int metric, const T *p, const T *q, int d) {
+  int32_t r = 0;
+  if (metric == 1) {
+    for (int i = 0; i < d; i++) r += (int32_t)p[i] * (int32_t)q[i];
+    return -(float)r;
+  }
+  for (int i = 0; i < d; i++) {
+    const int32_t t = (int32_t)p[i] - (int32_t)q[i];
+    r += t * t;
+  }
+  return (float)r;
+}
+
+// metric: bit 0 = inner product; bits 4-5 = element type of the rows (0 float32, 1 uint8, 2 int8)
 float host_distance(int metric, const float *p, const float *q, int d) {
-  return metric == 1 ? mips_ref_order(p, q, d) : l2_ref_order(p, q, d);
+  const int dtype = (metric >> 4) & 3;
+  if (dtype == 1) return byte_distance<uint8_t>(metric & 1, (const uint8_t *)p, (const uint8_t *)q, d);
+  if (dtype == 2) return byte_distance<int8_t>(metric & 1, (const int8_t *)p, (const int8_t *)q, d);
+  return (metric & 1) ? mips_ref_order(p, q, d) : l2_ref_order(p, q, d);
 }
 
 static inline uint32_t fkey(float f) {
@@ -317,7 +337,7 @@ void build_search(const BuildView &V, const HostGraph &G, int32_t index, Scratch
       S.table[loc] = a;
       kept[nk++] = a;
       const char *pv = (const char *)V.vec(a);  // the search is latency bound: get the misses in flight
-      for (int64_t off = 0; off < V.d * 4; off += 64) __builtin_prefetch(pv + off);
+      for (int64_t off = 0; off < V.stride * 4; off += 64) __builtin_prefetch(pv + off);
     }
     for (int i = 0; i < nk; i++) {
       const int32_t a = kept[i];
@@ -612,12 +632,13 @@ void vamana_build(const float *pts, int64_t stride, int64_t d, int metric, int64
 // ------------------------------------------------------------------------------------------------
 // index layout
 // ------------------------------------------------------------------------------------------------
-void build_host_index(HostIndex &H, const float *points, const float *labels, int shard, int nshards,
+void build_host_index(HostIndex &H, const void *points, const float *labels, int shard, int nshards,
                       std::vector<HostPart *> *pending) {
   BuildSpec &s = H.spec;
   if (s.n <= 0 || s.d <= 0) throw std::runtime_error("empty point set");
   if (s.threads <= 0) s.threads = default_threads();
-  s.stride = ((s.d * 4 + 63) / 64) * 16;  // 64-byte rows (point_range.h:39-44), zero padded
+  const int64_t esz = s.dtype == 0 ? 4 : 1;     // bytes per element of the caller's rows and of the stored rows
+  s.stride = ((s.d * esz + 63) / 64) * 16;      // 64-byte rows (point_range.h:39-44), zero padded; in 32-bit words
   H.sorted = (s.kind == 2 || s.kind == 3 || s.kind == 4);
   H.vamana_leaves = (s.kind == 1 || s.kind == 3 || s.kind == 4);
   const int64_t n = s.n;
@@ -629,7 +650,7 @@ void build_host_index(HostIndex &H, const float *points, const float *labels, in
   H.labels.resize((size_t)n);
   H.decoding.resize((size_t)n);
   parallel_for(n, s.threads, [&](int64_t r) {
-    memcpy(H.pts.data() + r * s.stride, points + order[r] * s.d, (size_t)s.d * 4);
+    memcpy(H.pts.data() + r * s.stride, (const char *)points + order[r] * s.d * esz, (size_t)(s.d * esz));
     H.labels[r] = labels[order[r]];
     H.decoding[r] = (uint32_t)order[r];
   });
@@ -759,7 +780,7 @@ void build_pending_on_host(HostIndex &H, std::vector<HostPart *> &pending) {
   std::vector<Job> jobs;
   for (HostPart *P : pending) {
     Job J;
-    J.V = BuildView{H.pts.data(), s.stride, s.d, s.metric, P->start, P->n, s.R, s.L, s.alpha};
+    J.V = BuildView{H.pts.data(), s.stride, s.d, s.metric | (s.dtype << 4), P->start, P->n, s.R, s.L, s.alpha};
     J.G = &P->g;
     jobs.push_back(std::move(J));
   }

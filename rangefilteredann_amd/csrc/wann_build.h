@@ -30,6 +30,7 @@ struct HostPart {
 
 struct BuildSpec {
   int kind = 0, metric = 0;
+  int dtype = 0;  // element type of the rows (wann.h WANN_DTYPE_*): float32, or uint8 / int8 bytes
   int64_t n = 0, d = 0, stride = 0;
   int32_t cutoff = 1000;
   double split_factor = 2, shift_factor = 0.5;
@@ -42,7 +43,8 @@ struct BuildSpec {
 struct HostIndex {
   BuildSpec spec;
   bool vamana_leaves = false, sorted = false;
-  std::vector<float> pts;          // n x stride, zero padded rows (label-sorted for tree kinds)
+  std::vector<float> pts;          // n x stride 32-bit words: zero padded rows (label-sorted for tree kinds); float32 values, or the
+                                   // d bytes of a uint8 / int8 row
   std::vector<float> labels;       // same order as pts
   std::vector<uint32_t> decoding;  // row -> original id
   std::vector<std::vector<int64_t>> offsets;  // WST bucket offsets per level
@@ -56,6 +58,7 @@ struct HostIndex {
 void parallel_for(int64_t n, int threads, const std::function<void(int64_t)> &f);
 int default_threads();
 
+// metric: bit 0 = inner product, bits 4-5 = element type of the rows behind p / q (0 float32, 1 uint8, 2 int8)
 float host_distance(int metric, const float *p, const float *q, int d);
 
 bool graph_file_load(const std::string &path, HostGraph &g);
@@ -73,7 +76,7 @@ void vamana_build(const float *pts, int64_t stride, int64_t d, int metric, int64
 // shard/nshards >= 0: only materialise (build + save) partitions p with p % nshards == shard.
 // pending != nullptr: graphs missing from the cache are NOT built here but returned in *pending
 // (the caller builds them, on the GPU or with build_pending_on_host, then calls save_built_graphs).
-void build_host_index(HostIndex &H, const float *points, const float *labels, int shard = -1,
+void build_host_index(HostIndex &H, const void *points, const float *labels, int shard = -1,
                       int nshards = 0, std::vector<HostPart *> *pending = nullptr);
 void build_pending_on_host(HostIndex &H, std::vector<HostPart *> &pending);
 void save_built_graphs(HostIndex &H, std::vector<HostPart *> &built, bool keep);

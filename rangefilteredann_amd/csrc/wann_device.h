@@ -42,6 +42,8 @@ struct IndexView {
   const int64_t *sup_shift;
   int64_t n;
   int32_t d, stride, rs, maxdeg, metric, kind, nlevels, cutoff, split, vamana_leaves;
+  int32_t dtype;  // element type of `points` (wann.h WANN_DTYPE_*): float32 rows, or uint8 / int8 rows of d bytes padded to a
+                  // multiple of 64 -- `stride` counts 32-bit words in every case and `points` is addressed in words
 };
 
 enum { T_EMPTY = 0, T_GRAPH = 1, T_BRUTE = 2, T_BRUTE_GATHER = 3, T_PARENT = 4 };

@@ -182,6 +182,7 @@ void upload_index(wann_index &I) {
   v.d = (int32_t)s.d;
   v.stride = (int32_t)s.stride;
   v.metric = s.metric;
+  v.dtype = s.dtype;
   v.kind = s.kind;
   v.cutoff = s.cutoff;
   v.split = (int32_t)s.split_factor;
@@ -541,7 +542,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     HIP_CHECK(hipEventRecord(W.ev_route, st));
   }
 
-  if (I.H.spec.kind == WANN_KIND_PREFILTER && nq >= 32 && !getenv("WANN_NO_GEMM"))
+  if (I.H.spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.H.spec.dtype == WANN_DTYPE_F32 && !getenv("WANN_NO_GEMM"))
     dense_prefilter(I, d_queries, nq, k, st);
 
   const bool may_brute = I.H.spec.kind != WANN_KIND_POSTFILTER && I.H.spec.kind != WANN_KIND_SUPER;
@@ -909,11 +910,12 @@ std::vector<float> bytes_to_float(int dtype, const void *src, int64_t count) {
   return out;
 }
 
-BuildSpec make_spec(int kind, int metric, int64_t n, int64_t d, int32_t cutoff, double split_factor,
+BuildSpec make_spec(int kind, int metric, int dtype, int64_t n, int64_t d, int32_t cutoff, double split_factor,
                     double shift_factor, const wann_build_params *bp, int threads) {
   BuildSpec s;
   s.kind = kind;
   s.metric = metric;
+  s.dtype = dtype;
   s.n = n;
   s.d = d;
   s.cutoff = cutoff;
@@ -950,33 +952,19 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
     fail(WANN_ERR_UNSUPPORTED, "point sets of 2^31 or more rows are not supported");
     return nullptr;
   }
-  // uint8 / int8 point sets (euclidian_point.h:44-60, mips_point.h:44-58: int32 accumulation, cast to float):
-  // the bytes become integer-valued fp32 rows; every partial sum then stays below 2^24, where fp32 arithmetic is
-  // exact in any order, so the fp32 kernels return exactly the reference's (float)int32 distances.
-  if (dtype != WANN_DTYPE_F32) {
-    const int64_t term = (metric == WANN_METRIC_MIPS && dtype == WANN_DTYPE_I8) ? 128 * 128 : 255 * 255;
-    if (d * term > ((int64_t)1 << 24)) {  // partial sums up to 2^24 inclusive are exact in fp32
-      fail(WANN_ERR_UNSUPPORTED, "uint8/int8 point sets are supported up to 258 dimensions (1024 for int8 inner products): beyond "
-                                 "that fp32 accumulation is no longer exact");
-      return nullptr;
-    }
-  }
+  // uint8 / int8 point sets (euclidian_point.h:44-60, mips_point.h:44-58: int32 accumulation, cast to float) are kept as
+  // BYTE rows on the device and scored with v_dot4 into exact int32 sums: any dimension, a quarter of the vector traffic.
   if (usable_devices() <= device || device < 0) {
     fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
     return nullptr;
-  }
-  std::vector<float> as_float;
-  if (dtype != WANN_DTYPE_F32) {
-    as_float = bytes_to_float(dtype, points, n * d);
-    points = as_float.data();
   }
   std::unique_ptr<wann_index> I(new wann_index);
   try {
     I->device = device;
     I->dtype = dtype;
-    I->H.spec = make_spec(kind, metric, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
+    I->H.spec = make_spec(kind, metric, dtype, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
     std::vector<HostPart *> pending;
-    build_host_index(I->H, (const float *)points, labels, -1, 0, &pending);
+    build_host_index(I->H, points, labels, -1, 0, &pending);
     upload_index(*I);
     if (!pending.empty()) build_pending(*I, pending);
   } catch (HipError &e) {
@@ -1085,19 +1073,13 @@ int64_t wann_device_bytes(const wann_index *I) { return I ? I->device_bytes : -1
 int wann_build_cache_shard(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
                            const float *labels, int32_t cutoff, double split_factor, double shift_factor,
                            const wann_build_params *bp, int shard, int nshards, int build_threads) {
-  std::vector<float> as_float;
-  if (dtype == WANN_DTYPE_U8 || dtype == WANN_DTYPE_I8) {
-    as_float = bytes_to_float(dtype, points, n * d);
-    points = as_float.data();
-  } else if (dtype != WANN_DTYPE_F32) {
-    return fail(WANN_ERR_INVALID, "unknown dtype");
-  }
+  if (dtype != WANN_DTYPE_F32 && dtype != WANN_DTYPE_U8 && dtype != WANN_DTYPE_I8) return fail(WANN_ERR_INVALID, "unknown dtype");
   if (!bp || !bp->cache_path || !*bp->cache_path) return fail(WANN_ERR_INVALID, "cache_path required");
   if (nshards <= 0 || shard < 0 || shard >= nshards) return fail(WANN_ERR_INVALID, "bad shard");
   try {
     HostIndex H;
-    H.spec = make_spec(kind, metric, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
-    build_host_index(H, (const float *)points, labels, shard, nshards);
+    H.spec = make_spec(kind, metric, dtype, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
+    build_host_index(H, points, labels, shard, nshards);
   } catch (std::exception &e) {
     return fail(WANN_ERR_INVALID, e.what());
   }
@@ -1113,8 +1095,9 @@ struct RawGraph {
   DevBuf<PartDesc> d_parts;
   int64_t n = 0, d = 0, subset_n = 0;
   int32_t maxdeg = 0;
-  void load(int device, int metric, const float *points, int64_t n_, int64_t d_, const int32_t *graph_rows, int64_t maxdeg_,
-            int64_t subset_start, int64_t subset_n_) {
+  // points: (n, d) rows of `dtype` elements (float32, or uint8 / int8 bytes: stored as byte rows)
+  void load(int device, int metric, const void *points, int64_t n_, int64_t d_, const int32_t *graph_rows, int64_t maxdeg_,
+            int64_t subset_start, int64_t subset_n_, int dtype = WANN_DTYPE_F32) {
     HIP_CHECK(hipSetDevice(device));
     I.device = device;
     hipDeviceProp_t prop;
@@ -1124,9 +1107,10 @@ struct RawGraph {
     d = d_;
     subset_n = subset_n_;
     maxdeg = (int32_t)maxdeg_;
-    const int64_t stride = ((d * 4 + 63) / 64) * 16;
+    const int64_t esz = dtype == WANN_DTYPE_F32 ? 4 : 1;
+    const int64_t stride = ((d * esz + 63) / 64) * 16;  // 32-bit words per row
     std::vector<float> pts((size_t)n * stride, 0.f);
-    for (int64_t i = 0; i < n; i++) memcpy(pts.data() + i * stride, points + i * d, (size_t)d * 4);
+    for (int64_t i = 0; i < n; i++) memcpy(pts.data() + i * stride, (const char *)points + i * d * esz, (size_t)(d * esz));
     const int rs = (int)(((maxdeg_ + 15) / 16) * 16);
     HostGraph g;
     g.n = subset_n;
@@ -1148,6 +1132,7 @@ struct RawGraph {
     I.view.rs = rs;
     I.view.maxdeg = (int32_t)maxdeg_;
     I.view.metric = metric;
+    I.view.dtype = dtype;
   }
   // one beam search per query (host buffers); cut_k > 0: the k / cut step of beamSearch.h:159-167 (first-generation core)
   void search(const float *queries, int64_t nq, const int64_t *query_ids, int64_t beam, int64_t limit, int64_t degree_limit,
@@ -1283,7 +1268,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
 // ---- unfiltered VamanaIndex (ParlayANN/python/vamana_index.cpp:42-76, ParlayANN/python/builder.cpp) ----------------
 namespace {
 // point file: uint32 n, uint32 d, then n * d elements (point_range.h:63-93)
-void read_point_file(const char *path, int dtype, std::vector<float> &out, int64_t &n, int64_t &d) {
+void read_point_file(const char *path, int dtype, std::vector<float> &out, int64_t &n, int64_t &d, std::vector<unsigned char> *raw_out = nullptr) {
   FILE *f = fopen(path, "rb");
   if (!f) throw std::runtime_error(std::string("cannot open point file ") + path);
   uint32_t head[2];
@@ -1303,6 +1288,7 @@ void read_point_file(const char *path, int dtype, std::vector<float> &out, int64
     memcpy(out.data(), raw.data(), cnt * 4);
   } else
     out = bytes_to_float(dtype, raw.data(), (int64_t)cnt);
+  if (raw_out) raw_out->swap(raw);
 }
 }  // namespace
 
@@ -1325,13 +1311,14 @@ wann_vamana *wann_vamana_open(int metric, int dtype, const char *data_path, cons
     std::unique_ptr<wann_vamana> V(new wann_vamana);
     V->dtype = dtype;
     std::vector<float> pts;
+    std::vector<unsigned char> raw;
     int64_t n = 0, d = 0;
-    read_point_file(data_path, dtype, pts, n, d);
+    read_point_file(data_path, dtype, pts, n, d, &raw);
     HostGraph g;
     if (!graph_file_load(graph_path, g)) throw std::runtime_error(std::string("cannot read graph file ") + graph_path);
     if (g.n != n) throw std::runtime_error("graph file and point file disagree on the number of points");
     if (g.maxdeg > 64) throw std::runtime_error("max_degree > 64 is not supported");
-    V->G.load(device, metric, pts.data(), n, d, g.rows.data(), g.maxdeg, 0, n);
+    V->G.load(device, metric, raw.data(), n, d, g.rows.data(), g.maxdeg, 0, n, dtype);
     return V.release();
   } catch (HipError &e) {
     fail(WANN_ERR_HIP, e.what());
@@ -1382,14 +1369,17 @@ int wann_vamana_build_file(int metric, int dtype, const char *data_path, const c
   try {
     std::vector<float> pts;
     int64_t n = 0, d = 0;
-    read_point_file(data_path, dtype, pts, n, d);
+    std::vector<unsigned char> raw;  // (byte point sets are built from their bytes: exact integer distances)
+    read_point_file(data_path, dtype, pts, n, d, &raw);
     if (n <= 0 || d <= 0) return fail(WANN_ERR_INVALID, "empty point file");
+
     // one Vamana graph over the points in file order = the stand-alone post-filter index's graph
     // (knn_index::build_index, vamana/index.h:123-313, BuildParams(R, L, alpha) types.h:94)
     std::vector<float> labels((size_t)n);
     for (int64_t i = 0; i < n; i++) labels[(size_t)i] = (float)i;
     wann_build_params bp{max_degree, limit, alpha, ""};
-    wann_index *I = wann_index_create(WANN_KIND_POSTFILTER, metric, WANN_DTYPE_F32, pts.data(), n, d, labels.data(), 1000, 2, 0.5, &bp, device, 0);
+    wann_index *I = wann_index_create(WANN_KIND_POSTFILTER, metric, dtype, dtype == WANN_DTYPE_F32 ? (const void *)pts.data() : (const void *)raw.data(), n, d,
+                                      labels.data(), 1000, 2, 0.5, &bp, device, 0);
     if (!I) return WANN_ERR_HIP;  // (message already set)
     const HostGraph &g = I->H.levels[0][0].g;
     const bool ok = g.n == n && graph_file_save(graph_out_path, g);

@@ -274,6 +274,82 @@ __device__ __forceinline__ float mips_pair(const float *__restrict__ prow, const
   return -r;
 }
 
+// --------------------------------------------------------------------------------------------
+// uint8 / int8 point sets (WANN_DT = 1 / 2: one translation unit per element type, see wann_kernels_u8.hip):
+// rows are BYTES (d elements, zero padded to a multiple of 64), `stride` still counts 32-bit words, distances
+// are exact int32 sums cast to float like the reference's (euclidian_point.h:44-60, mips_point.h:44-58) for any
+// dimension.  A lane pair owns a candidate; lane h takes the 16-byte chunks 2t + h; v_dot4 does four
+// multiply-adds per instruction; squared L2 = sum a^2 + sum q^2 - 2 sum a q (each sum an exact integer).
+// Both lanes of the pair return the distance.
+// --------------------------------------------------------------------------------------------
+#ifndef WANN_DT
+#define WANN_DT 0  // 0 = float32 rows, 1 = uint8, 2 = int8
+#endif
+#if WANN_DT != 0
+__device__ __forceinline__ int dot4_acc(uint32_t a, uint32_t b, int c) {
+#if WANN_DT == 1
+  return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
+#else
+  return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+#endif
+}
+
+template <int METRIC>
+__device__ __forceinline__ float byte_pair(const float *__restrict__ prow, const float *qv, int stride_words, int h) {
+  const int chunks = stride_words >> 3;  // 16-byte chunks per lane (the row has stride_words / 4 of them)
+  int ab = 0, aa = 0, qq = 0;
+  for (int t0 = 0; t0 < chunks; t0 += 8) {
+    uint4 buf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (t0 + j < chunks) buf[j] = *reinterpret_cast<const uint4 *>(prow + 4 * (2 * (t0 + j) + h));
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (t0 + j < chunks) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(qv + 4 * (2 * (t0 + j) + h));
+        const uint4 p = buf[j];
+        ab = dot4_acc(p.x, q.x, ab);
+        ab = dot4_acc(p.y, q.y, ab);
+        ab = dot4_acc(p.z, q.z, ab);
+        ab = dot4_acc(p.w, q.w, ab);
+        if (METRIC == 0) {
+          aa = dot4_acc(p.x, p.x, aa);
+          aa = dot4_acc(p.y, p.y, aa);
+          aa = dot4_acc(p.z, p.z, aa);
+          aa = dot4_acc(p.w, p.w, aa);
+          qq = dot4_acc(q.x, q.x, qq);
+          qq = dot4_acc(q.y, q.y, qq);
+          qq = dot4_acc(q.z, q.z, qq);
+          qq = dot4_acc(q.w, q.w, qq);
+        }
+      }
+  }
+  const int mine = METRIC == 0 ? (aa + qq - 2 * ab) : ab;
+  const int both = mine + __shfl_xor(mine, 1);
+  return METRIC == 0 ? (float)both : -(float)both;
+}
+
+// the query's elements (integer-valued floats) packed four to a word, as the rows are
+__device__ __forceinline__ float pack_query_word(const float *q, int64_t base, int i, int d) {
+  uint32_t w = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int e = 4 * i + j;
+    if (e < d) w |= ((uint32_t)(int)q[base + e] & 0xffu) << (8 * j);
+  }
+  return __uint_as_float(w);
+}
+#endif
+
+// staged query word i of `stride` (zero padded): a float for float32 rows, four packed elements for byte rows
+__device__ __forceinline__ float stage_query_word(const float *queries, int64_t qrow, int i, int d) {
+#if WANN_DT == 0
+  return (i < d) ? queries[qrow * d + i] : 0.f;
+#else
+  return pack_query_word(queries, qrow * d, i, d);
+#endif
+}
+
 // Pull the cache lines of rows ids_lds[first..first+count) towards the L2 without consuming them:
 // one dword per 128-B line, result unused (the loads of the rows that follow then hit the cache
 // instead of paying a second serial HBM round trip).
@@ -295,6 +371,22 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
                                                 float *scratch_lds, const float *qv, int cnt,
                                                 int64_t row_off) {
   const int lane = lane_id();
+#if WANN_DT != 0
+  {
+    const int h = lane & 1;
+    for (int base = 0; base < cnt; base += 32) {
+      const int s = base + (lane >> 1);
+      const bool act = s < cnt;
+      const int id = act ? ids_lds[s] : 0;
+      const float dd = byte_pair<METRIC>(ix.points + (row_off + id) * (int64_t)ix.stride, qv, ix.stride, h);
+      if (act && h) scratch_lds[s] = dd;
+    }
+    WAVE_SYNC();
+    const float r = (lane < cnt) ? scratch_lds[lane] : 0.f;
+    WAVE_SYNC();
+    return r;
+  }
+#endif
   if (METRIC == 1) {
     const int h = lane & 1;
     const int np = (((ix.d + 3) >> 2) + 1) >> 1;  // wave-uniform
@@ -886,6 +978,9 @@ __device__ __forceinline__ float wave_distances_own(const IndexView &ix, int a, 
     const int id = (base + s < nt) ? ev : 0;  // idle pairs score node 0: no branches
     const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
     float dd;
+#if WANN_DT != 0
+    dd = byte_pair<METRIC>(prow, qv, ix.stride, h);
+#else
     if (METRIC == 1) {
       const int np = (((ix.d + 3) >> 2) + 1) >> 1;
       switch (np) {  // wave-uniform
@@ -903,6 +998,7 @@ __device__ __forceinline__ float wave_distances_own(const IndexView &ix, int a, 
         default: dd = l2_pair<16>(prow, qv, D8, h, true); break;
       }
     }
+#endif
     // the result sits in the odd lane of the pair (in both for the inner product): the owner pulls it
     const float back = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((((r - base) << 1) | 1) << 2, __builtin_bit_cast(int, dd)));
     if (now) mine = back;

@@ -108,3 +108,7 @@ if __name__ == "__main__":
     make("u8_l2", "Euclidian", g(n).astype(np.uint8), g(nq).astype(np.uint8), distinct_labels(n, 9), R=16, L=32, cutoff=200, elem="UInt8")
     g = sift_like(n, d, 8765)
     make("i8_mips", "mips", (g(n) - 128).astype(np.int8), (g(nq) - 128).astype(np.int8), distinct_labels(n, 10), R=16, L=32, cutoff=200, elem="Int8")
+    # 512 bytes per row: sums beyond 2^24, exact only with the reference's int32 accumulation
+    n, d, nq = 640, 512, 16
+    g = sift_like(n, d, 2468)
+    make("u8_l2_d512", "Euclidian", g(n).astype(np.uint8), g(nq).astype(np.uint8), distinct_labels(n, 11), R=16, L=32, cutoff=200, elem="UInt8")

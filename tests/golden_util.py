@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = {"sift_l2": "FloatEuclidian", "unit_mips": "FloatMips", "u8_l2": "UInt8Euclidian", "i8_mips": "Int8Mips"}
+FIXTURES = {"sift_l2": "FloatEuclidian", "unit_mips": "FloatMips", "u8_l2": "UInt8Euclidian", "i8_mips": "Int8Mips",
+            "u8_l2_d512": "UInt8Euclidian"}  # (512 bytes per row: beyond what float32 accumulation represents exactly)
 KINDS = {
     "VamanaRangeFilterTreeIndex": dict(split_factor=2),
     "SuperOptimizedPostfilterTreeIndex": dict(split_factor=2, shift_factor=0.5),

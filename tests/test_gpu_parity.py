@@ -156,6 +156,12 @@ CASES = [
     ("PostfilterVamanaIndex", "FloatEuclidian", sift_like, 64, 4000, dict()),
     ("RangeFilterTreeIndex", "FloatEuclidian", sift_like, 48, 4000, dict(cutoff=300, split_factor=2)),
     ("PrefilterIndex", "FloatMips", unit_mixture, 100, 4000, dict()),
+    # byte rows (python_bindings.cpp:234-237): dimensions beyond what float32 accumulation represents exactly
+    ("VamanaRangeFilterTreeIndex", "UInt8Euclidian", sift_like, 300, 4000, dict(cutoff=400, split_factor=2)),
+    ("SuperOptimizedPostfilterTreeIndex", "Int8Mips", lambda n, d, s: (lambda m, g=sift_like(n, d, s): g(m) - 128.0), 520, 3000,
+     dict(cutoff=300, split_factor=2, shift_factor=0.5)),
+    ("VamanaRangeFilterTreeIndex", "Int8Euclidian", lambda n, d, s: (lambda m, g=sift_like(n, d, s): g(m) - 128.0), 70, 3000, dict(cutoff=300, split_factor=3)),
+    ("PrefilterIndex", "UInt8Mips", sift_like, 200, 3000, dict()),
 ]
 
 
@@ -289,6 +295,7 @@ BUILD_CASES = [
     ("VamanaRangeFilterTreeIndex", "FloatMips", unit_mixture, 100, 4000, dict(cutoff=400, split_factor=2), 24, 48),
     ("SuperOptimizedPostfilterTreeIndex", "FloatEuclidian", sift_like, 40, 3000, dict(cutoff=300, split_factor=2, shift_factor=0.5), 16, 100),
     ("PostfilterVamanaIndex", "FloatEuclidian", sift_like, 64, 20000, dict(), 64, 500),
+    ("VamanaRangeFilterTreeIndex", "UInt8Euclidian", sift_like, 512, 3000, dict(cutoff=400, split_factor=2), 24, 48),  # byte rows
 ]
 
 

@@ -18,4 +18,7 @@ for i, s in enumerate(starts):
         g = lambda k: (re.search(rf"\.{k}:\s*(\S+)", blk) or [None, "?"])[1]
         name = g("name")
         if len(sys.argv) > 1 and sys.argv[1] not in name: continue
-        print(f"{name[:70]:70s} vgpr {g('vgpr_count'):>4} sgpr {g('sgpr_count'):>4} scratch {g('private_segment_fixed_size'):>5} spill {g('vgpr_spill_count'):>3} sgpr_spill {g('sgpr_spill_count'):>4} lds {g('group_segment_fixed_size')}")
+        m = re.match(r":?\s*(\d+)", blk)
+        agpr = m.group(1) if m else "?"
+        print(f"{name[:60]:60s} vgpr+agpr {g('vgpr_count'):>4} (agpr {agpr:>3}) sgpr {g('sgpr_count'):>4} scratch {g('private_segment_fixed_size'):>5} "
+              f"spill {g('vgpr_spill_count'):>3} sgpr_spill {g('sgpr_spill_count'):>4}")

@@ -393,14 +393,27 @@ inline float pdist(const BuildCtx &C, int64_t a, int64_t b) {
                   (uint32_t)C.d);
 }
 
-// robustPrune (vamana/index.h:61-108).  cand carries distances to p.  Ties break by id here.
+// Order of exactly equidistant candidates.  The reference sorts by distance ONLY with std::sort (vamana/index.h:77-78,
+// graph.h:106), so equal keys end up wherever libstdc++'s introsort leaves them -- a deterministic function of the
+// input sequence.  ORC_REF_TIES=1 (read per build) restates exactly that (same std::sort, same sequence, same
+// comparator): byte-identical graphs also on integer-valued data, checked against files the real reference wrote.
+// Default: ties break by id, the canonical form every builder of the product (host and GPU) uses.
+inline bool ref_ties() {
+  const char *e = getenv("ORC_REF_TIES");
+  return e && *e && *e != '0';
+}
+inline bool dist_only_less(const pid &a, const pid &b) { return a.second < b.second; }
+
+// robustPrune (vamana/index.h:61-108).  cand carries distances to p (the visited list of the build search, sorted by
+// (dist, id) like the reference's, or the incoming sources in batch order).
 std::vector<int32_t> robust_prune(const BuildCtx &C, const Graph &G, int32_t p,
                                   std::vector<pid> cand, bool add = true) {
   if (add) {
     const int32_t *row = G.row(p);
     for (int32_t i = 0; i < row[0]; i++) cand.emplace_back(row[1 + i], pdist(C, row[1 + i], p));
   }
-  std::sort(cand.begin(), cand.end(), pid_less);
+  if (ref_ties()) std::sort(cand.begin(), cand.end(), dist_only_less);
+  else std::sort(cand.begin(), cand.end(), pid_less);
   std::vector<int32_t> out;
   out.reserve(C.R);
   size_t idx = 0;
@@ -544,7 +557,8 @@ void vamana_build(const BuildCtx &C, Graph &G, int threads) {
     int32_t *row = G.row(i);
     std::vector<pid> nb(row[0]);
     for (int32_t j = 0; j < row[0]; j++) nb[j] = pid(row[1 + j], pdist(C, i, row[1 + j]));
-    std::sort(nb.begin(), nb.end(), pid_less);
+    if (ref_ties()) std::sort(nb.begin(), nb.end(), dist_only_less);
+    else std::sort(nb.begin(), nb.end(), pid_less);
     for (int32_t j = 0; j < row[0]; j++) row[1 + j] = nb[j].first;
   });
 }

@@ -392,13 +392,29 @@ void build_search(const BuildView &V, const HostGraph &G, int32_t index, Scratch
 }
 
 // robustPrune (vamana/index.h:61-108); cand = (key(dist to p, id)); ties by id
+// Order of exactly equidistant candidates.  The reference sorts by distance ONLY with std::sort (vamana/index.h:77-78,
+// graph.h:106): equal keys end up wherever libstdc++'s introsort leaves them, a deterministic function of the input
+// sequence.  WANN_REF_TIES=1 reproduces that -- the same std::sort on the same sequence (visited list in (dist, id)
+// order, then the current out-neighbours; sources in batch order) with the same comparator -- so that the host builder
+// writes the reference's graph files byte for byte also for integer-valued vectors (SIFT).  Default: ties break by id,
+// the canonical form the GPU builder produces.
+static bool ref_ties() {
+  const char *e = getenv("WANN_REF_TIES");
+  return e && *e && *e != '0';
+}
+static inline bool dist_only_less(uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); }
+
+// cand: the visited list of the build search (any order) when from_search, else the incoming sources in batch order
 void robust_prune(const BuildView &V, const HostGraph &G, int32_t p, std::vector<uint64_t> &cand, bool add,
-                  std::vector<int32_t> &out) {
+                  std::vector<int32_t> &out, bool from_search = false) {
+  const bool ref = ref_ties();
+  if (ref && from_search) std::sort(cand.begin(), cand.end());  // the reference keeps its visited list sorted by (dist, id)
   if (add) {
     const int32_t *row = G.row(p);
     for (int32_t i = 0; i < row[0]; i++) cand.push_back(mkkey(V.dist(row[1 + i], p), row[1 + i]));
   }
-  std::sort(cand.begin(), cand.end());
+  if (ref) std::sort(cand.begin(), cand.end(), dist_only_less);
+  else std::sort(cand.begin(), cand.end());
   out.clear();
   const size_t nc = cand.size();
   std::vector<char> dead(nc, 0);
@@ -540,7 +556,7 @@ static void build_many(std::vector<Job> &jobs, int threads) {
       Scratch &S = tls_scratch;
       build_search(J.V, *J.G, index, S);
       std::vector<uint64_t> cand(S.visited);
-      robust_prune(J.V, *J.G, index, cand, true, J.fresh[items[it].second]);
+      robust_prune(J.V, *J.G, index, cand, true, J.fresh[items[it].second], true);
     });
     double t2 = now();
     tA += t2 - t1;
@@ -616,7 +632,8 @@ static void build_many(std::vector<Job> &jobs, int threads) {
     int32_t *row = J.G->row(i);
     std::vector<uint64_t> nb((size_t)row[0]);
     for (int32_t x = 0; x < row[0]; x++) nb[x] = mkkey(J.V.dist(i, row[1 + x]), row[1 + x]);
-    std::sort(nb.begin(), nb.end());
+    if (ref_ties()) std::sort(nb.begin(), nb.end(), dist_only_less);
+    else std::sort(nb.begin(), nb.end());
     for (int32_t x = 0; x < row[0]; x++) row[1 + x] = key_id(nb[x]);
   });
 }

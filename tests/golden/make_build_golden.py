@@ -4,7 +4,8 @@ Pins the graph BUILDER: (1) parlay::random_permutation<int>(n), the insertion or
 printed by perm_probe.cpp compiled against the parlay headers under /root/reference; (2) the graph cache
 files the reference's PostfilterVamanaIndex writes for two inputs with continuous coordinates (no two
 candidates of a prune or neighbour sort are exactly equidistant there, so the result does not depend on
-libstdc++'s std::sort tie order).  Only data is written.  Usage:  python tests/golden/make_build_golden.py
+libstdc++'s std::sort tie order) and for one integer-valued input full of ties (reproduced by the builders'
+reference-tie-order mode: ORC_REF_TIES / WANN_REF_TIES).  Only data is written.  Usage:  python tests/golden/make_build_golden.py
 """
 import hashlib
 import os
@@ -27,9 +28,11 @@ PERM_HASHED = [20000, 65536, 100001, 1000000]
 REF_INC = "/root/reference/ParlayANN/parlaylib/include"
 
 
-def build_case(ref, name, metric, n, d, R, L, seed, out):
+def build_case(ref, name, metric, n, d, R, L, seed, out, integer=False):
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((n, d)).astype(np.float32)
+    if integer:  # few distinct distances: exact ties in every prune and neighbour sort (libstdc++'s std::sort order decides)
+        X = rng.integers(0, 6, size=(n, d)).astype(np.float32)
     if metric == "mips":
         X /= np.linalg.norm(X, axis=1, keepdims=True)
     labels = ((rng.permutation(n) + 0.5) / n).astype(np.float32)
@@ -65,5 +68,6 @@ if __name__ == "__main__":
     shutil.rmtree(tmp)
     build_case(ref, "gauss_l2", "l2", 700, 12, 12, 30, 5, out)
     build_case(ref, "unit_mips", "mips", 8200, 6, 6, 14, 6, out)  # n >= 8192: the bucketed permutation
+    build_case(ref, "int_l2", "l2", 900, 8, 12, 30, 7, out, integer=True)  # integer-valued vectors: distance ties everywhere
     np.savez_compressed(os.path.join(HERE, "build_golden.npz"), **out)
     print("wrote build_golden.npz:", len(out), "arrays")

@@ -58,6 +58,31 @@ def test_builder_writes_the_references_graph_file(wa, tmp_path, name):
     assert open(cdir + os.listdir(cdir)[0], "rb").read() == data[f"{name}|file"].tobytes()
 
 
+def test_integer_valued_graph_equals_the_references_with_its_tie_order(oracle, wa, tmp_path, monkeypatch):
+    """Integer-valued vectors (SIFT-like): prunes and neighbour sorts are full of exactly equidistant candidates, and
+    the reference orders them by libstdc++'s std::sort on distance alone (vamana/index.h:77-78, graph.h:106).  In
+    reference-tie-order mode the oracle's builder and the product's host builder reproduce the file the REAL
+    reference wrote; in the default (ties by id) mode they agree with each other and differ from it."""
+    import golden_util as gu
+    data = gu.load_build()
+    name = "int_l2"
+    X, labels, (R, L, metric) = data[f"{name}|X"], data[f"{name}|labels"], data[f"{name}|meta"]
+    want = data[f"{name}|file"].tobytes()
+    n, d = X.shape
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WANN_REF_TIES", mode)
+        monkeypatch.setenv("ORC_REF_TIES", mode)
+        cdir = str(tmp_path / ("m" + mode)) + "/"
+        os.makedirs(cdir)
+        wa.build_cache_shard(1, int(metric), X, labels, 1000, 2, 0.5, wa.BuildParams(int(R), int(L), 1.0, cdir), 0, 1, 3)
+        got = open(cdir + os.listdir(cdir)[0], "rb").read()
+        rows = oracle.vamana_build(oracle.pad_rows(X), d, int(metric), 0, n, int(R), int(L), 1.0)
+        opath = str(tmp_path / ("oracle" + mode + ".bin"))
+        oracle.graph_save(opath, rows)
+        assert open(opath, "rb").read() == got, f"mode {mode}: host builder and oracle builder disagree"
+        assert (got == want) == (mode == "1"), f"mode {mode}"
+
+
 def test_sharded_build_equals_whole_build(wa, tmp_path):
     n, d = 2500, 32
     X = sift_like(n, d, 3)(n)

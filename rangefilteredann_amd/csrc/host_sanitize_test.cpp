@@ -12,6 +12,8 @@
 
 #include "../../include/wann.h"
 #include "wann_build.h"
+#include "wann_stdsort.h"
+#include <algorithm>
 
 using namespace wann;
 
@@ -117,6 +119,48 @@ int main(int argc, char **argv) {
     for (int32_t x : p) {
       CHECK(x >= 0 && x < n && !seen[(size_t)x]);
       if (x >= 0 && x < n) seen[(size_t)x] = 1;
+    }
+  }
+  // the restated std::sort (wann_stdsort.h) against libstdc++'s own, distance-only comparator, sequences full of ties
+  {
+    auto check = [&](std::vector<uint64_t> v) {
+      std::vector<uint64_t> want = v, got = v;
+      std::sort(want.begin(), want.end(), DistOnlyLess());
+      int32_t stack[128];
+      std_sort_emulated(got.data(), (int)got.size(), stack, DistOnlyLess());
+      CHECK(got == want);
+      want = v;
+      got = v;
+      std::sort(want.begin(), want.end(), FullKeyLess());
+      std_sort_emulated(got.data(), (int)got.size(), stack, FullKeyLess());
+      CHECK(got == want);
+    };
+    for (int n = 0; n <= 2600; n += (n < 70 ? 1 : 37)) {
+      for (int levels : {1, 2, 5, 40, 1 << 20}) {  // number of distinct distances
+        std::vector<uint64_t> v((size_t)n);
+        for (int i = 0; i < n; i++) v[(size_t)i] = ((uint64_t)(rng() % (uint32_t)levels) << 32) | ((uint64_t)(uint32_t)i << 1);
+        check(v);
+        std::sort(v.begin(), v.end());
+        check(v);  // already sorted
+        std::reverse(v.begin(), v.end());
+        check(v);
+      }
+    }
+    // a median-of-three killer (exhausts the depth limit: the heapsort branch) and an organ pipe
+    for (int n : {64, 512, 2048, 4096}) {
+      std::vector<uint64_t> v((size_t)n);
+      const int k = n / 2;
+      for (int i = 1; i <= k; i++) {
+        if (i & 1) {
+          v[(size_t)i - 1] = (uint64_t)i << 32;
+          v[(size_t)i] = (uint64_t)(k + i) << 32;
+        }
+        v[(size_t)(k + i - 1)] = (uint64_t)(2 * i) << 32;
+      }
+      for (int i = 0; i < n; i++) v[(size_t)i] |= (uint64_t)(uint32_t)i << 1;
+      check(v);
+      for (int i = 0; i < n; i++) v[(size_t)i] = ((uint64_t)(i < n / 2 ? i : n - i) << 32) | ((uint64_t)(uint32_t)i << 1);
+      check(v);
     }
   }
   // the C ABI's argument validation (no device needed for these paths) lives in wann_host.cpp and is covered by tests/test_abi.py

@@ -34,6 +34,7 @@ struct BuildArgs {
   unsigned long long *big_sb;                 // per wave slot global candidate buffer for those
   int64_t big_cap;
   int32_t big;                                // 1: k_build_reverse walks the fallback list with big_sb
+  int32_t ref_ties;                           // order exactly equidistant candidates as the reference's std::sort does (wann_stdsort.h)
 };
 
 int launch_build_insert(const BuildArgs &a, int blocks, int table_lds, void *stream);

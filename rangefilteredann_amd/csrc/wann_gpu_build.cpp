@@ -94,6 +94,10 @@ void gpu_build_graphs(const IndexView &view, int32_t *d_graph, const std::vector
   HIP_CHECK(hipHostMalloc((void **)&h_ints, 16 * sizeof(int32_t)));
 
   BuildArgs A{};
+  {  // WANN_REF_TIES=1: equidistant candidates in the order the reference's std::sort leaves them (wann_stdsort.h)
+    const char *e = getenv("WANN_REF_TIES");
+    A.ref_ties = (e && *e && *e != '0') ? 1 : 0;
+  }
   A.ix = view;
   A.ix.graph = d_graph;
   A.graph_rw = d_graph;

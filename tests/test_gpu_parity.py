@@ -349,6 +349,43 @@ def test_gpu_builder_writes_the_references_graph_file(wa, gpu, tmp_path, monkeyp
     assert open(cdir + os.listdir(cdir)[0], "rb").read() == data[f"{name}|file"].tobytes()
 
 
+def test_gpu_builder_reference_tie_order(wa, gpu, tmp_path, monkeypatch):
+    """Integer-valued vectors: prunes and neighbour sorts are full of exactly equidistant candidates, which the reference
+    orders with std::sort on the distance alone.  With WANN_REF_TIES=1 the GPU builder runs the restated std::sort
+    (wann_stdsort.h) on the same sequences and (1) writes the file the REAL reference wrote for the integer-valued golden
+    input, (2) agrees with the host builder (which calls std::sort itself) on a SIFT-like tree of graphs -- uint8 rows too."""
+    import os
+    data = gu.load_build()
+    name = "int_l2"
+    X, labels, (R, L, metric) = data[f"{name}|X"], data[f"{name}|labels"], data[f"{name}|meta"]
+    monkeypatch.setenv("WANN_REF_TIES", "1")
+    monkeypatch.delenv("WANN_HOST_BUILD", raising=False)
+    cdir = str(tmp_path / "golden") + "/"
+    os.makedirs(cdir)
+    wa.PostfilterVamanaIndexFloatEuclidian(X, labels, wa.BuildParams(int(R), int(L), 1.0, cdir))
+    assert os.listdir(cdir) == [data[f"{name}|file_name"].tobytes().decode()]
+    assert open(cdir + os.listdir(cdir)[0], "rb").read() == data[f"{name}|file"].tobytes()
+    monkeypatch.setenv("WANN_REF_TIES", "0")
+    ddir = str(tmp_path / "default") + "/"
+    os.makedirs(ddir)
+    wa.PostfilterVamanaIndexFloatEuclidian(X, labels, wa.BuildParams(int(R), int(L), 1.0, ddir))
+    assert open(ddir + os.listdir(ddir)[0], "rb").read() != data[f"{name}|file"].tobytes()  # (ties by id: another valid graph)
+    monkeypatch.setenv("WANN_REF_TIES", "1")
+    for sfx, d, n in (("FloatEuclidian", 128, 5000), ("UInt8Euclidian", 64, 3000)):
+        X2 = sift_like(n, d, 78)(n)
+        lab2 = distinct_labels(n, 14)
+        gdir, hdir = str(tmp_path / ("gpu" + sfx)) + "/", str(tmp_path / ("host" + sfx)) + "/"
+        os.makedirs(gdir), os.makedirs(hdir)
+        monkeypatch.delenv("WANN_HOST_BUILD", raising=False)
+        getattr(wa, "VamanaRangeFilterTreeIndex" + sfx)(X2, lab2, cutoff=500, split_factor=2, build_params=wa.BuildParams(24, 48, 1.0, gdir))
+        monkeypatch.setenv("WANN_HOST_BUILD", "1")
+        getattr(wa, "VamanaRangeFilterTreeIndex" + sfx)(X2, lab2, cutoff=500, split_factor=2, build_params=wa.BuildParams(24, 48, 1.0, hdir))
+        gf, hf = sorted(os.listdir(gdir)), sorted(os.listdir(hdir))
+        assert gf == hf and len(gf) > 0
+        for f in gf:
+            assert open(gdir + f, "rb").read() == open(hdir + f, "rb").read(), f"{sfx} {f}: GPU and host builders differ in reference tie order"
+
+
 # ------------------------------------------------------------------------------------------
 # multi-bucket query methods (fenwick, three_split) and the ratio fallback, against the oracle
 # ------------------------------------------------------------------------------------------

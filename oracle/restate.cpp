@@ -395,12 +395,12 @@ inline float pdist(const BuildCtx &C, int64_t a, int64_t b) {
 
 // Order of exactly equidistant candidates.  The reference sorts by distance ONLY with std::sort (vamana/index.h:77-78,
 // graph.h:106), so equal keys end up wherever libstdc++'s introsort leaves them -- a deterministic function of the
-// input sequence.  ORC_REF_TIES=1 (read per build) restates exactly that (same std::sort, same sequence, same
-// comparator): byte-identical graphs also on integer-valued data, checked against files the real reference wrote.
-// Default: ties break by id, the canonical form every builder of the product (host and GPU) uses.
-inline bool ref_ties() {
+// input sequence.  The restatement does exactly that (same std::sort, same sequence, same comparator): byte-identical
+// graphs also on integer-valued data, checked against files the real reference wrote.  ORC_REF_TIES=0 (read per build):
+// ties break by id instead (what the product's builders do under WANN_REF_TIES=0).
+inline bool ref_ties() {  // default on; ORC_REF_TIES=0: ties by id
   const char *e = getenv("ORC_REF_TIES");
-  return e && *e && *e != '0';
+  return !(e && *e == '0');
 }
 inline bool dist_only_less(const pid &a, const pid &b) { return a.second < b.second; }
 

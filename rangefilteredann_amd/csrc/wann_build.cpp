@@ -394,13 +394,13 @@ void build_search(const BuildView &V, const HostGraph &G, int32_t index, Scratch
 // robustPrune (vamana/index.h:61-108); cand = (key(dist to p, id)); ties by id
 // Order of exactly equidistant candidates.  The reference sorts by distance ONLY with std::sort (vamana/index.h:77-78,
 // graph.h:106): equal keys end up wherever libstdc++'s introsort leaves them, a deterministic function of the input
-// sequence.  WANN_REF_TIES=1 reproduces that -- the same std::sort on the same sequence (visited list in (dist, id)
-// order, then the current out-neighbours; sources in batch order) with the same comparator -- so that the host builder
-// writes the reference's graph files byte for byte also for integer-valued vectors (SIFT).  Default: ties break by id,
-// the canonical form the GPU builder produces.
-static bool ref_ties() {
+// sequence.  The builders reproduce that -- the same std::sort on the same sequence (visited list in (dist, id) order,
+// then the current out-neighbours; sources in batch order) with the same comparator; the GPU builder runs a restatement
+// of the algorithm, wann_stdsort.h -- so that the graph files equal the reference's byte for byte also for
+// integer-valued vectors (SIFT).  WANN_REF_TIES=0 switches to "ties break by id" (a test hook).
+static bool ref_ties() {  // default on; WANN_REF_TIES=0: ties by id
   const char *e = getenv("WANN_REF_TIES");
-  return e && *e && *e != '0';
+  return !(e && *e == '0');
 }
 static inline bool dist_only_less(uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); }
 

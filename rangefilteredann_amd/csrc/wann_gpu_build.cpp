@@ -94,9 +94,9 @@ void gpu_build_graphs(const IndexView &view, int32_t *d_graph, const std::vector
   HIP_CHECK(hipHostMalloc((void **)&h_ints, 16 * sizeof(int32_t)));
 
   BuildArgs A{};
-  {  // WANN_REF_TIES=1: equidistant candidates in the order the reference's std::sort leaves them (wann_stdsort.h)
+  {  // equidistant candidates in the order the reference's std::sort leaves them (wann_stdsort.h); WANN_REF_TIES=0: by id
     const char *e = getenv("WANN_REF_TIES");
-    A.ref_ties = (e && *e && *e != '0') ? 1 : 0;
+    A.ref_ties = (e && *e == '0') ? 0 : 1;
   }
   A.ix = view;
   A.ix.graph = d_graph;

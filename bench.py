@@ -376,7 +376,7 @@ def main():
     alg_bytes = 4 * (R + 1) * hops_all + d * 4 * cmps_all + 4 * labs_all
     kern_s = kern_ms / 1e3
     achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
-    traffic, traffic_source = measured_traffic(beam, mult, n, gnq // world)
+    traffic, traffic_source = measured_traffic(beam, mult, n, gnq // world, args.fraction)
     roofline = dict(bound="hbm", kernel="k_search", achieved=round(achieved, 1), peak=HBM_PEAK_GBS * world, unit="GB/s",
                     frac=round(achieved / (HBM_PEAK_GBS * world), 4), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_step=int(alg_bytes / args.steps),
@@ -477,7 +477,7 @@ def other_configs(want, cache, ncpu):
     return out
 
 
-def measured_traffic(beam, mult, n, nq_per_gpu):
+def measured_traffic(beam, mult, n, nq_per_gpu, fraction=-3):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc cannot run inside this
     process); returned only when that pass measured this very configuration, with its source named."""
     best = None
@@ -489,7 +489,8 @@ def measured_traffic(beam, mult, n, nq_per_gpu):
             pj = json.load(open(os.path.join(prof, name)))
         except Exception:
             continue
-        if pj.get("beam") == beam and pj.get("mult") == mult and pj.get("n") == n and pj.get("nq", 10_000) == nq_per_gpu:
+        if (pj.get("beam") == beam and pj.get("mult") == mult and pj.get("n") == n and pj.get("nq", 10_000) == nq_per_gpu
+                and pj.get("fraction", -3) == fraction):
             best = (pj.get("hbm_bytes_per_launch"), f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE pass of this configuration, not this run)")
     return best if best else (None, None)
 

@@ -88,6 +88,7 @@ typedef struct {
   double search_kernel_ms; /* HIP-event time summed over beam-search kernel launches    */
   int64_t recovered_continuations; /* searches a follow-up launch ran because the companion launch's pollers did not
                                       serve them (launches serialised by the runtime / a profiler); 0 normally     */
+  int64_t gemm_unproven; /* of gemm_queries: sent on to the exact scan because the MFMA scores could not prove the top k */
 } wann_counters;
 
 typedef struct wann_index wann_index;

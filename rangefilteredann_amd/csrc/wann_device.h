@@ -68,6 +68,7 @@ struct Counters {
   // not part of the reference's operation count)
   unsigned long long spec_searches, spec_hops, spec_dist_cmps;
   unsigned long long poll_timeouts;  // pollers that gave up waiting (serialised launches); the host re-queues what they left unserved
+  unsigned long long gemm_queries, gemm_unproven;  // dense prefilter path: queries scored on the matrix cores / of those, sent on to the exact scan
 };
 
 struct RouteArgs {

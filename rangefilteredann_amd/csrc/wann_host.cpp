@@ -146,8 +146,10 @@ struct wann_index {
   bool have_norms = false;
   DevBuf<GemmGroup> g_groups;
   DevBuf<GemmTile> g_tiles;
-  DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_sel_pos, g_sel_cnt;
-  DevBuf<float> g_scores, g_sel_cut;
+  DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_q_slot, g_q_rank, g_plan, g_cand_cnt;
+  DevBuf<unsigned long long> g_slot_key, g_cand_key;
+  DevBuf<float> g_cand_cut;
+  DevBuf<unsigned int> g_thr;
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
   wann_counters last{};
@@ -351,71 +353,14 @@ int method_code(const char *m) {
   return M_FENWICK;  // range_filter_tree.h:76-82: everything else falls through to fenwick
 }
 
-// PrefilterIndex batches in which many queries share a window: score those windows as Q x P^T GEMMs on
-// the matrix cores, keep 32 candidates per query, re-rank them exactly; everything else (and every
-// query whose top-k cannot be proven from the MFMA scores) goes through the exact scan kernel.
+// PrefilterIndex batches in which many queries share a window: those windows are scored as Q x P^T GEMMs on the
+// matrix cores (wann_gemm_kernels.hip), ~32 candidates per query are kept and re-ranked exactly; everything else (and
+// every query whose top-k cannot be proven from the MFMA scores) goes through the exact scan kernel.  Grouping,
+// tile planning and the hand-over to the exact scan all happen on the device: the host enqueues six launches and
+// never waits.
 void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, hipStream_t st) {
   Workspace &W = I.ws;
-  std::vector<Task> tasks((size_t)nq);
-  HIP_CHECK(hipMemcpyAsync(tasks.data(), W.tasks.p, (size_t)nq * sizeof(Task), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  // group the queries by window in O(nq): open-addressing table over (a, b), then a counting sort by group
-  // (a comparison sort of 10 000 queries cost 0.3 ms of a 1 ms batch); groups in first-seen order, members ascending
-  std::vector<int32_t> order;
-  {
-    size_t cap = 64;
-    while (cap < (size_t)nq * 2) cap <<= 1;
-    std::vector<int32_t> slot_group(cap, -1), grp_of((size_t)nq, -1), grp_cnt;
-    std::vector<int64_t> slot_a(cap), slot_b(cap);
-    int32_t members = 0;
-    for (int64_t q = 0; q < nq; q++) {
-      if (tasks[q].mode != T_BRUTE_GATHER) continue;
-      const int64_t a = tasks[q].a, b = tasks[q].b;
-      uint64_t h = ((uint64_t)a * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)b * 0xC2B2AE3D27D4EB4Full);
-      size_t pos = (size_t)(h >> 20) & (cap - 1);
-      while (slot_group[pos] >= 0 && (slot_a[pos] != a || slot_b[pos] != b)) pos = (pos + 1) & (cap - 1);
-      if (slot_group[pos] < 0) {
-        slot_group[pos] = (int32_t)grp_cnt.size();
-        slot_a[pos] = a;
-        slot_b[pos] = b;
-        grp_cnt.push_back(0);
-      }
-      grp_of[(size_t)q] = slot_group[pos];
-      grp_cnt[(size_t)slot_group[pos]]++;
-      members++;
-    }
-    std::vector<int32_t> start(grp_cnt.size() + 1, 0);
-    for (size_t g = 0; g < grp_cnt.size(); g++) start[g + 1] = start[g] + grp_cnt[g];
-    order.resize((size_t)members);
-    for (int64_t q = 0; q < nq; q++)
-      if (grp_of[(size_t)q] >= 0) order[(size_t)start[(size_t)grp_of[(size_t)q]]++] = (int32_t)q;
-  }
-  std::vector<GemmGroup> groups;
-  std::vector<GemmTile> tiles;
-  std::vector<int32_t> gq, tq_group, tq_local, rest;
-  int64_t soff = 0;
-  const int64_t budget = (int64_t)2 << 30;  // floats (8 GiB of scores)
-  for (size_t i = 0; i < order.size();) {
-    size_t j = i;
-    while (j < order.size() && tasks[order[j]].a == tasks[order[i]].a && tasks[order[j]].b == tasks[order[i]].b) j++;
-    const int64_t w = tasks[order[i]].b - tasks[order[i]].a, qc = (int64_t)(j - i), wp = (w + 3) & ~(int64_t)3;
-    if (qc >= 16 && w >= 64 && k <= kSelect / 2 && soff + qc * wp <= budget && I.view.stride <= 128) {
-      GemmGroup g{tasks[order[i]].a, tasks[order[i]].b, soff, (int32_t)gq.size(), (int32_t)qc};
-      for (int64_t t0 = 0; t0 < qc; t0 += 128)
-        for (int64_t p0 = 0; p0 < w; p0 += kGemmPointChunk) tiles.push_back(GemmTile{(int32_t)groups.size(), (int32_t)t0, p0});
-      for (size_t t = i; t < j; t++) {
-        tq_group.push_back((int32_t)groups.size());
-        tq_local.push_back((int32_t)(t - i));
-        gq.push_back(order[t]);
-      }
-      soff += qc * wp;
-      groups.push_back(g);
-    } else {
-      for (size_t t = i; t < j; t++) rest.push_back(order[t]);
-    }
-    i = j;
-  }
-  if (groups.empty()) return;
+  if (k > kSelect / 2 || I.view.stride > 128 || (I.view.stride & 15)) return;
   if (!I.have_norms) {
     I.d_pnorm2.ensure((size_t)I.view.n);
     I.d_pnorm2_max.ensure(1);
@@ -423,44 +368,55 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
     if (launch_point_norms(I.view, I.d_pnorm2.p, I.d_pnorm2_max.p, st)) throw HipError(std::string("k_point_norms: ") + gemm_launch_last_error());
     I.have_norms = true;
   }
-  I.g_groups.upload(groups);
-  I.g_tiles.upload(tiles);
-  I.g_gq.upload(gq);
-  I.g_tq_group.upload(tq_group);
-  I.g_tq_local.upload(tq_local);
-  I.g_scores.ensure((size_t)soff);
-  I.g_sel_pos.ensure(gq.size() * kSelect);
-  I.g_sel_cnt.ensure(gq.size());
-  I.g_sel_cut.ensure(gq.size());
-  // the exact scan keeps the ungrouped queries; k_rerank appends the unproven ones to the same list
-  const int32_t nrest = (int32_t)rest.size();
-  if (nrest) HIP_CHECK(hipMemcpyAsync(W.list_brute.p, rest.data(), rest.size() * 4, hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipMemcpyAsync(W.ints.p + I_BRUTE_COUNT, &nrest, 4, hipMemcpyHostToDevice, st));
+  size_t cap = 64;
+  while (cap < (size_t)nq * 2) cap <<= 1;
+  I.g_slot_key.ensure(cap);
+  I.g_slot_count.ensure(cap);
+  I.g_slot_group.ensure(cap);
+  I.g_q_slot.ensure((size_t)nq);
+  I.g_q_rank.ensure((size_t)nq);
+  I.g_plan.ensure(P_INTS);
+  I.g_groups.ensure((size_t)nq / kGroupMinQueries + 1);
+  // tiles: sum over groups of ceil(qc / 128) * nch <= (nq / 128 + groups) * kMaxChunks
+  I.g_tiles.ensure(((size_t)nq / 128 + (size_t)nq / kGroupMinQueries + 2) * kMaxChunks);
+  I.g_gq.ensure((size_t)nq);
+  I.g_tq_group.ensure((size_t)nq);
+  I.g_tq_local.ensure((size_t)nq);
+  I.g_thr.ensure((size_t)nq);
+  I.g_cand_key.ensure((size_t)nq * kMaxChunks * kCandCap);
+  I.g_cand_cnt.ensure((size_t)nq * kMaxChunks);
+  I.g_cand_cut.ensure((size_t)nq * kMaxChunks);
   GemmArgs ga{};
   ga.ix = I.view;
   ga.queries = d_queries;
+  ga.tasks = W.tasks.p;
+  ga.nq = nq;
+  ga.slot_key = I.g_slot_key.p;
+  ga.slot_count = I.g_slot_count.p;
+  ga.slot_group = I.g_slot_group.p;
+  ga.cap_mask = (int32_t)(cap - 1);
+  ga.q_slot = I.g_q_slot.p;
+  ga.q_rank = I.g_q_rank.p;
+  ga.plan = I.g_plan.p;
   ga.groups = I.g_groups.p;
   ga.tiles = I.g_tiles.p;
-  ga.ntiles = (int32_t)tiles.size();
   ga.gq = I.g_gq.p;
   ga.tq_group = I.g_tq_group.p;
   ga.tq_local = I.g_tq_local.p;
-  ga.ntq = (int64_t)gq.size();
   ga.pnorm2 = I.d_pnorm2.p;
   ga.pnorm2_max_bits = I.d_pnorm2_max.p;
-  ga.scores = I.g_scores.p;
-  ga.sel_pos = I.g_sel_pos.p;
-  ga.sel_cnt = I.g_sel_cnt.p;
-  ga.sel_cut = I.g_sel_cut.p;
+  ga.cand_key = I.g_cand_key.p;
+  ga.cand_cnt = I.g_cand_cnt.p;
+  ga.cand_cut = I.g_cand_cut.p;
+  ga.thr_shared = I.g_thr.p;
   ga.k = k;
   ga.out_key = W.out_key.p;
   ga.out_cnt = W.out_cnt.p;
-  ga.fallback_list = W.list_brute.p;
-  ga.fallback_count = W.ints.p + I_BRUTE_COUNT;
-  if (launch_gemm_scores(ga, st)) throw HipError(std::string("k_gemm_scores: ") + gemm_launch_last_error());
-  if (launch_select_rerank(ga, st)) throw HipError(std::string("k_select/k_rerank: ") + gemm_launch_last_error());
-  HIP_CHECK(hipStreamSynchronize(st));  // host vectors above back the async uploads
-  I.last.gemm_queries = (int64_t)gq.size();
+  ga.brute_list = W.list_brute.p;
+  ga.brute_count = W.ints.p + I_BRUTE_COUNT;
+  if (launch_group_windows(ga, W.ctr.p, st)) throw HipError(std::string("k_group_*: ") + gemm_launch_last_error());
+  if (launch_gemm_select(ga, I.num_cus, st)) throw HipError(std::string("k_gemm_select: ") + gemm_launch_last_error());
+  if (launch_rerank(ga, W.ctr.p, st)) throw HipError(std::string("k_rerank: ") + gemm_launch_last_error());
 }
 
 void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int64_t nq, int64_t qid_base,
@@ -855,6 +811,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.spec_dist_cmps = (int64_t)W.h_ctr->spec_dist_cmps;
   I.last.rounds = rounds;
   I.last.recovered_continuations = recovered;
+  I.last.gemm_queries = (int64_t)W.h_ctr->gemm_queries;
+  I.last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");

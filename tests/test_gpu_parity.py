@@ -558,7 +558,7 @@ def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
     class CTR(C.Structure):
         _fields_ = [(f, C.c_int64) for f in ("beam_searches", "hops", "dist_cmps", "brute_rows", "label_reads", "rounds", "spec_searches",
                                             "spec_hops", "spec_dist_cmps", "gemm_queries")] + [("device_ms", C.c_double), ("search_kernel_ms", C.c_double),
-                                                                                              ("recovered_continuations", C.c_int64)]
+                                                                                              ("recovered_continuations", C.c_int64), ("gemm_unproven", C.c_int64)]
 
     lib.wann_index_create.restype = C.c_void_p
     lib.wann_index_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double,
@@ -639,6 +639,51 @@ def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sf
         ids2, dists2 = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
         assert pi.counters()["gemm_queries"] == 0
         assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2)
+
+
+@pytest.mark.parametrize("sfx,d,style", [("FloatMips", 100, "unit"), ("FloatEuclidian", 128, "sift"), ("FloatEuclidian", 24, "unit"),
+                                         ("FloatMips", 7, "drift")])
+def test_dense_prefilter_slices_and_tiles(wa, gpu, monkeypatch, sfx, d, style):
+    """Windows longer than one slice (2 048 positions), longer than eight (the slice grows), groups of more than 128 queries
+    (several tiles), duplicates (equal scores), and labels that correlate with the geometry (the best candidates all sit at
+    the end of the window: every list overflows again and again).  The MFMA path must return exactly what the exact scan does."""
+    rng = np.random.default_rng(5)
+    n = 42000
+    if style == "sift":
+        X = sift_like(n, d, 3)(n)
+        Q = sift_like(n, d, 3)(700)
+    else:
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Q = rng.standard_normal((700, d)).astype(np.float32)
+        if style == "unit":
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X[1000:1040] = X[1000]  # duplicates
+    labels = rng.permutation(n).astype(np.float32)
+    if style == "drift":  # sorted by the score of the first query family: later labels = better candidates
+        order = np.argsort(X @ Q[0])
+        labels = np.empty(n, dtype=np.float32)
+        labels[order] = np.arange(n, dtype=np.float32)
+        Q[:] = Q[0] * (1 + 0.01 * rng.standard_normal((700, 1))).astype(np.float32)
+    nq = Q.shape[0]
+    W = np.zeros((nq, 2))
+    W[:300] = (100.5, 25100.5)       # 25 000 positions: eight slices of 3 200; three query tiles
+    W[300:520] = (30000.5, 35000.5)  # 5 000 positions: three slices; two tiles
+    W[520:560] = (-1, 1e9)           # everything
+    W[560:660] = (500.5, 700.5)      # 200 positions: one short slice
+    W[660:] = (7.5, 50.5)            # below the minimum window: exact scan
+    pi = getattr(wa, "PrefilterIndex" + sfx)(X, labels)
+    for k in (10, 1):
+        monkeypatch.delenv("WANN_NO_GEMM", raising=False)
+        ids, dists = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
+        c = pi.counters()
+        assert c["gemm_queries"] == 660, c
+        monkeypatch.setenv("WANN_NO_GEMM", "1")
+        ids2, dists2 = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
+        assert pi.counters()["gemm_queries"] == 0
+        assert np.array_equal(dists, dists2), (style, k, int((dists != dists2).any(axis=1).sum()), c)
+        assert np.array_equal(ids, ids2), (style, k, int((ids != ids2).any(axis=1).sum()), c)
+        if style == "unit" and d == 100:
+            assert c["gemm_unproven"] < 66, c  # the proof must hold for nearly every query on well-separated data
 
 
 @pytest.mark.parametrize("n,d", [(1, 4), (2, 3), (7, 5), (300, 5), (300, 17)])

@@ -145,11 +145,9 @@ struct wann_index {
   DevBuf<unsigned int> d_pnorm2_max;
   bool have_norms = false;
   DevBuf<GemmGroup> g_groups;
-  DevBuf<GemmTile> g_tiles;
-  DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_q_slot, g_q_rank, g_plan, g_cand_cnt;
-  DevBuf<unsigned long long> g_slot_key, g_cand_key;
-  DevBuf<float> g_cand_cut;
-  DevBuf<unsigned int> g_thr;
+  DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan, g_sel_pos, g_sel_cnt;
+  DevBuf<unsigned long long> g_slot_key, g_score_used;
+  DevBuf<float> g_scores, g_sel_cut;
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
   wann_counters last{};
@@ -356,7 +354,7 @@ int method_code(const char *m) {
 // PrefilterIndex batches in which many queries share a window: those windows are scored as Q x P^T GEMMs on the
 // matrix cores (wann_gemm_kernels.hip), ~32 candidates per query are kept and re-ranked exactly; everything else (and
 // every query whose top-k cannot be proven from the MFMA scores) goes through the exact scan kernel.  Grouping,
-// tile planning and the hand-over to the exact scan all happen on the device: the host enqueues six launches and
+// tile planning and the hand-over to the exact scan all happen on the device: the host enqueues seven launches and
 // never waits.
 void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, hipStream_t st) {
   Workspace &W = I.ws;
@@ -373,19 +371,21 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   I.g_slot_key.ensure(cap);
   I.g_slot_count.ensure(cap);
   I.g_slot_group.ensure(cap);
+  I.g_slot_list.ensure((size_t)nq);
   I.g_q_slot.ensure((size_t)nq);
   I.g_q_rank.ensure((size_t)nq);
   I.g_plan.ensure(P_INTS);
+  I.g_score_used.ensure(1);
   I.g_groups.ensure((size_t)nq / kGroupMinQueries + 1);
-  // tiles: sum over groups of ceil(qc / 128) * nch <= (nq / 128 + groups) * kMaxChunks
-  I.g_tiles.ensure(((size_t)nq / 128 + (size_t)nq / kGroupMinQueries + 2) * kMaxChunks);
   I.g_gq.ensure((size_t)nq);
   I.g_tq_group.ensure((size_t)nq);
   I.g_tq_local.ensure((size_t)nq);
-  I.g_thr.ensure((size_t)nq);
-  I.g_cand_key.ensure((size_t)nq * kMaxChunks * kCandCap);
-  I.g_cand_cnt.ensure((size_t)nq * kMaxChunks);
-  I.g_cand_cut.ensure((size_t)nq * kMaxChunks);
+  I.g_sel_pos.ensure((size_t)nq * kSelect);
+  I.g_sel_cnt.ensure((size_t)nq);
+  I.g_sel_cut.ensure((size_t)nq);
+  // the score matrices of all groups: nq x n floats at most, capped at 4 GiB (groups beyond that take the exact scan)
+  const size_t score_cap = (size_t)std::min<unsigned long long>((unsigned long long)nq * (unsigned long long)(I.view.n + 3), 1ull << 30);
+  I.g_scores.ensure(score_cap);
   GemmArgs ga{};
   ga.ix = I.view;
   ga.queries = d_queries;
@@ -394,29 +394,31 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   ga.slot_key = I.g_slot_key.p;
   ga.slot_count = I.g_slot_count.p;
   ga.slot_group = I.g_slot_group.p;
+  ga.slot_list = I.g_slot_list.p;
   ga.cap_mask = (int32_t)(cap - 1);
   ga.q_slot = I.g_q_slot.p;
   ga.q_rank = I.g_q_rank.p;
   ga.plan = I.g_plan.p;
+  ga.score_used = I.g_score_used.p;
   ga.groups = I.g_groups.p;
-  ga.tiles = I.g_tiles.p;
   ga.gq = I.g_gq.p;
   ga.tq_group = I.g_tq_group.p;
   ga.tq_local = I.g_tq_local.p;
   ga.pnorm2 = I.d_pnorm2.p;
   ga.pnorm2_max_bits = I.d_pnorm2_max.p;
-  ga.cand_key = I.g_cand_key.p;
-  ga.cand_cnt = I.g_cand_cnt.p;
-  ga.cand_cut = I.g_cand_cut.p;
-  ga.thr_shared = I.g_thr.p;
+  ga.scores = I.g_scores.p;
+  ga.score_cap = (int64_t)score_cap;
+  ga.sel_pos = I.g_sel_pos.p;
+  ga.sel_cnt = I.g_sel_cnt.p;
+  ga.sel_cut = I.g_sel_cut.p;
   ga.k = k;
   ga.out_key = W.out_key.p;
   ga.out_cnt = W.out_cnt.p;
   ga.brute_list = W.list_brute.p;
   ga.brute_count = W.ints.p + I_BRUTE_COUNT;
   if (launch_group_windows(ga, W.ctr.p, st)) throw HipError(std::string("k_group_*: ") + gemm_launch_last_error());
-  if (launch_gemm_select(ga, I.num_cus, st)) throw HipError(std::string("k_gemm_select: ") + gemm_launch_last_error());
-  if (launch_rerank(ga, W.ctr.p, st)) throw HipError(std::string("k_rerank: ") + gemm_launch_last_error());
+  if (launch_gemm_scores(ga, I.num_cus, st)) throw HipError(std::string("k_gemm_scores: ") + gemm_launch_last_error());
+  if (launch_select_rerank(ga, W.ctr.p, st)) throw HipError(std::string("k_select_scores / k_rerank: ") + gemm_launch_last_error());
 }
 
 void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int64_t nq, int64_t qid_base,

@@ -51,6 +51,7 @@ struct GemmArgs {
   unsigned long long *out_key;
   int32_t *out_cnt;
   int32_t *brute_list, *brute_count;  // exact scan: ungrouped queries + queries whose top-k could not be proven
+  unsigned long long *prof;           // dev tool (make PROFILE=1): phase-cycle sums of k_gemm_scores
 };
 
 int launch_point_norms(const IndexView &ix, float *norm2, unsigned int *max_bits, void *stream);

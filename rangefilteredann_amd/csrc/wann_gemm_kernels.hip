@@ -36,6 +36,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned long long kEmptySlot = ~0ull;
+#ifdef WANN_GEMM_PROF  // dev tool (make PROFILE=1): cycles per phase of k_gemm_scores, summed over waves into GemmArgs::prof
+#define GPROF_T(v) const unsigned long long v = __builtin_readcyclecounter();
+#define GPROF_ADD(i, a, b) prof_acc[i] += (b) - (a);
+#else
+#define GPROF_T(v)
+#define GPROF_ADD(i, a, b)
+#endif
 
 constexpr float kInf = __builtin_inff();
 
@@ -199,6 +206,10 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
   const bool mips = ix.metric == 1;
   const float scale = mips ? -1.f : -2.f;
   const int ntiles = A.plan[P_NTILES], ng = A.plan[P_NGROUPS];
+#ifdef WANN_GEMM_PROF
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tk0 = __builtin_readcyclecounter();
+#endif
 
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     int glo = 0, ghi = ng - 1;  // the last group whose first tile is <= t
@@ -254,12 +265,13 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
       }
     }
     __syncthreads();
-    // score rows of this lane: register reg of an MFMA tile holds row (reg & 3) + 8 (reg >> 2) + 4 half.  Byte offsets
-    // from the tile's first row stay below 2^32 (k_group_plan), so a store is base + 32-bit offset.
-    float *srow0 = A.scores + grp.soff + (int64_t)(q0 + 32 * wv) * wp;
-    const int rows_left = grp.qcount - q0 - 32 * wv;  // rows >= this are beyond the group
-    const f32x4 qn4[4] = {*reinterpret_cast<const f32x4 *>(qn + 32 * wv + 4 * half), *reinterpret_cast<const f32x4 *>(qn + 32 * wv + 8 + 4 * half),
-                          *reinterpret_cast<const f32x4 *>(qn + 32 * wv + 16 + 4 * half), *reinterpret_cast<const f32x4 *>(qn + 32 * wv + 24 + 4 * half)};
+    // The MFMA tile has the points as rows and the queries as columns: this lane holds query 32 wv + col, and register
+    // reg of tile j the window position 32 j + (reg & 3) + 8 (reg >> 2) + 4 half: four consecutive positions per
+    // 16-byte store, sixteen stores per step, all from one row pointer.
+    const int myrow = q0 + 32 * wv + col;
+    const bool live = myrow < grp.qcount;
+    float *srow = A.scores + grp.soff + (int64_t)(live ? myrow : q0) * wp + 4 * half;
+    const float qn1 = qn[32 * wv + col];
     // The next point block travels HBM -> registers while the MFMA loop of the current one runs (one wave per SIMD:
     // the 512-register budget is all ours), and registers -> bf16 pairs -> LDS after the barrier.  Its row numbers
     // were put in the LDS one step earlier, so no load depends on another load.
@@ -280,6 +292,7 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
     WANN_FETCH(p_begin)
     f32x16 acc[4];
     for (int64_t c0 = p_begin; c0 < p_end; c0 += 128) {
+      GPROF_T(t0)
       // (the barrier that ended the previous step: nobody reads Ps / base / rid any more)
 #pragma unroll
       for (int p = 0; p < 2; p++) {
@@ -298,7 +311,9 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
         base[tid] = mips ? 0.f : pre_n;
         rid[tid] = pre_rid;
       }
+      GPROF_T(t1)
       __syncthreads();
+      GPROF_T(t2)
       WANN_FETCH(c0 + 128)  // unconditional (row numbers are clamped): a conditional fetch would make the compiler wait for it here
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -329,32 +344,47 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
           }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bl[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], a_hi, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a_lo, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a_hi, acc[j], 0, 0, 0);
         // the reads of step s + 1 go first, the 12 MFMAs of step s run over them
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      const float bj4[4] = {base[col], base[32 + col], base[64 + col], base[96 + col]};
+      GPROF_T(t3)
+      if (live) {
+        const bool full = c0 + 128 <= p_end;  // (wave-uniform) else: the last block of the window, which ends inside it
 #pragma unroll
-      for (int g = 0; g < 4; g++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = 8 * g + 4 * half + r;
-          if (row < rows_left) {
-            float *dst = srow0 + (uint32_t)row * (uint32_t)wp + c0 + col;
+          for (int g = 0; g < 4; g++) {
+            const int p4 = 32 * j + 8 * g;  // + 4 half: in srow and below
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(base + p4 + 4 * half);
+            f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (c0 + 32 * j + col < p_end) dst[32 * j] = fmaf(scale, acc[j][4 * g + r], bj4[j]) + qn4[g][r];
+            for (int r = 0; r < 4; r++) o[r] = fmaf(scale, acc[j][4 * g + r], b4[r]) + qn1;
+            // rows are padded to four floats: a group of four positions is either inside the padded row or outside
+            if (full || c0 + p4 + 4 * half < wp) *reinterpret_cast<f32x4 *>(srow + c0 + p4) = o;
           }
-        }
+      }
+      GPROF_T(t4)
       __syncthreads();  // every wave is done with Ps / base / rid
+      GPROF_T(t5)
+      GPROF_ADD(0, t0, t1) GPROF_ADD(1, t1, t2) GPROF_ADD(2, t2, t3) GPROF_ADD(3, t3, t4) GPROF_ADD(4, t4, t5)
     }
   }
+#ifdef WANN_GEMM_PROF
+  prof_acc[5] = __builtin_readcyclecounter() - tk0;
+  if (lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(A.prof + i, prof_acc[i]);
+#endif
 #undef WANN_FETCH
 }
 

@@ -148,6 +148,7 @@ struct wann_index {
   DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan, g_sel_pos, g_sel_cnt;
   DevBuf<unsigned long long> g_slot_key, g_score_used;
   DevBuf<float> g_scores, g_sel_cut;
+  DevBuf<unsigned long long> g_prof;
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
   wann_counters last{};
@@ -416,9 +417,20 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   ga.out_cnt = W.out_cnt.p;
   ga.brute_list = W.list_brute.p;
   ga.brute_count = W.ints.p + I_BRUTE_COUNT;
+#ifdef WANN_GEMM_PROF
+  I.g_prof.ensure(8);
+  HIP_CHECK(hipMemsetAsync(I.g_prof.p, 0, 64, st));
+  ga.prof = I.g_prof.p;
+#endif
   if (launch_group_windows(ga, W.ctr.p, st)) throw HipError(std::string("k_group_*: ") + gemm_launch_last_error());
   if (launch_gemm_scores(ga, I.num_cus, st)) throw HipError(std::string("k_gemm_scores: ") + gemm_launch_last_error());
   if (launch_select_rerank(ga, W.ctr.p, st)) throw HipError(std::string("k_select_scores / k_rerank: ") + gemm_launch_last_error());
+#ifdef WANN_GEMM_PROF
+  unsigned long long h[8];
+  HIP_CHECK(hipMemcpyAsync(h, I.g_prof.p, 64, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  fprintf(stderr, "k_gemm_scores cycles summed over waves: stage %llu barrier %llu fetch+mfma %llu store %llu barrier %llu kernel %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+#endif
 }
 
 void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int64_t nq, int64_t qid_base,

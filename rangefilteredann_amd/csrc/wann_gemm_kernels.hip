@@ -388,9 +388,10 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
 #undef WANN_FETCH
 }
 
-// One wave per grouped query.  The kSelect best (score, position) keys live sorted in the registers of
-// lanes 0 .. kSelect-1; a row is streamed 1024 scores at a time (four 16-byte loads per lane in flight)
-// and the few scores below the current cut are inserted one by one with a ballot + one-lane shift.
+// One wave per grouped query.  The kSelect best scores live sorted in lanes 0 .. kSelect-1 (order-preserving score
+// bits in one register, window positions in another; equal scores stay in scan order = position order); a row is
+// streamed 1024 scores at a time (four 16-byte loads per lane in flight) and the few scores below the current cut
+// are inserted one by one with a ballot + one-lane shift.
 __global__ __launch_bounds__(256) void k_select_scores(GemmArgs A) {
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   const int64_t ntq = A.plan[P_NTQ];
@@ -398,38 +399,52 @@ __global__ __launch_bounds__(256) void k_select_scores(GemmArgs A) {
     const GemmGroup grp = A.groups[A.tq_group[tq]];
     const int64_t w = grp.b - grp.a, wp = (w + 3) & ~(int64_t)3;
     const float *srow = A.scores + grp.soff + (int64_t)A.tq_local[tq] * wp;
-    u64 top = ~0ull, thr = ~0ull;  // ~0 = empty slot; thr = key in lane kSelect-1
+    uint32_t top_s = 0xffffffffu, thr = 0xffffffffu;  // 0xffffffff (no float maps to it) = empty slot; thr = lane kSelect-1
+    int top_p = 0, filled = 0;
+    f32x4 vn[4];  // the next 1024 scores travel while the current ones are examined
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t off = j * 256 + 4 * lane;
+      vn[j] = (off < wp) ? *reinterpret_cast<const f32x4 *>(srow + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int64_t c0 = 0; c0 < wp; c0 += 1024) {
       f32x4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int64_t off = c0 + j * 256 + 4 * lane;
-        v[j] = (off < wp) ? *reinterpret_cast<const f32x4 *>(srow + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[j] = vn[j];
+        const int64_t off = c0 + 1024 + j * 256 + 4 * lane;
+        vn[j] = (off < wp) ? *reinterpret_cast<const f32x4 *>(srow + off) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int cmp = 0; cmp < 4; cmp++) {
           const int64_t pos = c0 + j * 256 + 4 * lane + cmp;
-          const u64 key = ((u64)fkey(v[j][cmp]) << 32) | ((u64)(uint32_t)pos << 1);
+          const uint32_t key = fkey(v[j][cmp]);
           u64 mask = ballot64(pos < w && key < thr);
           while (mask) {
-            const u64 ck = rdlane64(key, ctz64(mask));
+            const int src = ctz64(mask);
             mask &= mask - 1;
+            const uint32_t ck = (uint32_t)rdlane((int)key, src);
             if (ck < thr) {  // wave-uniform; thr may have dropped since the ballot
-              const int p = popc64(ballot64(top < ck));  // top is sorted: a prefix of the lanes
-              const u64 up = wave_shr1(top);
-              if (lane < kSelect) top = (lane == p) ? ck : (lane > p ? up : top);
-              thr = rdlane64(top, kSelect - 1);
+              const int p = popc64(ballot64(top_s <= ck));  // top is sorted: a prefix of the lanes
+              const int cp = (int)(c0 + j * 256 + cmp) + 4 * src;
+              const uint32_t up_s = (uint32_t)__builtin_amdgcn_update_dpp((int)top_s, (int)top_s, 0x138, 0xf, 0xf, false);
+              const int up_p = __builtin_amdgcn_update_dpp(top_p, top_p, 0x138, 0xf, 0xf, false);
+              if (lane < kSelect) {
+                top_s = (lane == p) ? ck : (lane > p ? up_s : top_s);
+                top_p = (lane == p) ? cp : (lane > p ? up_p : top_p);
+              }
+              filled += filled < kSelect;
+              thr = (uint32_t)rdlane((int)top_s, kSelect - 1);
             }
           }
         }
     }
-    const int m = popc64(ballot64(top != ~0ull));
-    if (lane < m) A.sel_pos[tq * kSelect + lane] = (int32_t)((uint32_t)top >> 1);
+    if (lane < filled) A.sel_pos[tq * kSelect + lane] = top_p;
     if (lane == 0) {
-      A.sel_cnt[tq] = m;
-      A.sel_cut[tq] = (m == kSelect && w > kSelect) ? funkey((uint32_t)(thr >> 32)) : 3.402823466e+38f;
+      A.sel_cnt[tq] = filled;
+      A.sel_cut[tq] = (filled == kSelect && w > kSelect) ? funkey(thr) : 3.402823466e+38f;
     }
   }
 }

@@ -190,6 +190,11 @@ struct BruteArgs {
   unsigned long long *out_key;
   int32_t *out_cnt;
   Counters *ctr;
+  // split scans (short lists): partial top-k lists [list position][slice][k rounded to even], their lengths, and one
+  // arrival counter per list position (zero between batches); part_key == nullptr: never split
+  unsigned long long *part_key;
+  int32_t *part_cnt, *part_done;
+  int64_t part_cap, part_slots;  // capacity of part_key (keys) and of part_cnt (slices)
 };
 
 struct FinalizeArgs {

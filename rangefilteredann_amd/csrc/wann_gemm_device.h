@@ -8,11 +8,12 @@ namespace wann {
 
 constexpr int kSelect = 32;      // candidates kept per query by MFMA score before the exact re-rank
 constexpr int kGemmPointChunk = 2048;  // window positions per tile (multiple of 128)
-constexpr int kGroupMinQueries = 16, kGroupMinWindow = 64;
+// (a window hands over three candidates per 64 positions: too short a window could never prove a top 10)
+constexpr int kGroupMinQueries = 16, kGroupMinWindow = 1024;
 
 struct GemmGroup {   // queries sharing the window [a, b) of the label argsort
   int64_t a, b;
-  int64_t soff;      // offset of the group's score matrix [qcount][(b - a) rounded up to 4] in `scores`
+  int64_t soff;      // offset (floats) of the group's block entries [qcount][steps of 128 positions][2][4] in `scores`
   int32_t qoff;      // the group's query rows are gq[qoff .. qoff + qcount)
   int32_t qcount;
   int32_t tile0;     // the group's tiles are tile0 .. tile0 + nqt * nch - 1: tile = tile0 + ch * nqt + qt
@@ -42,11 +43,11 @@ struct GemmArgs {
   int32_t *tq_local;
   const float *pnorm2;
   const unsigned int *pnorm2_max_bits;
-  float *scores;
+  float *scores;      // what k_gemm_scores hands to k_select_scores: per query, step and half wave the four smallest scores
   int64_t score_cap;  // floats; groups that do not fit any more are left to the exact scan
   int32_t *sel_pos;   // [ntq][kSelect] window-relative positions
   int32_t *sel_cnt;
-  float *sel_cut;     // score of the worst selected candidate (FLT_MAX when the whole window was taken)
+  float *sel_cut;     // every position that was not selected scores at least this (FLT_MAX: nothing was left out)
   int32_t k;
   unsigned long long *out_key;
   int32_t *out_cnt;

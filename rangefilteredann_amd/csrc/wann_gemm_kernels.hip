@@ -9,8 +9,12 @@
 //   k_gemm_scores    per (window group, 128-query tile, 2 048-position slice): S = Q . P^T on
 //                    v_mfma_f32_32x32x16_bf16 with both operands split into two bf16 terms (q = q1 + q2 + ...;
 //                    three products q1 p1 + q1 p2 + q2 p1, fp32 accumulate: 2^-16 relative instead of bf16's 2^-8, at
-//                    3/16 of the fp32-MFMA cost), scores -q.p (MIPS) or |q|^2 + |p|^2 - 2 q.p (L2)
-//   k_select_scores  per query: the 32 best scores of its window
+//                    3/16 of the fp32-MFMA cost), scores -q.p (MIPS) or |p|^2 - 2 q.p (L2; |q|^2 joins later).
+//                    The scores never reach memory: every lane owns 64 of them per step (one query, 64 window
+//                    positions) and keeps their four smallest in registers (min / max insertion, no branches; the
+//                    position travels in the six low mantissa bits); one 16-byte store per lane and step leaves
+//   k_select_scores  per query: the 32 best of its blocks' (three smallest) entries; the fourth smallest of every block
+//                    bounds what the block did not hand over
 //   k_rerank         per query: exact reference-order distances of those 32 candidates, ordered by
 //                    (dist, id), first k; plus a proof that no unselected point can belong to the
 //                    top k (score error bound); queries that cannot be proven fall back to
@@ -44,7 +48,7 @@ constexpr unsigned long long kEmptySlot = ~0ull;
 #define GPROF_ADD(i, a, b)
 #endif
 
-constexpr float kInf = __builtin_inff();
+constexpr float kHuge = 3.0e38f, kHugeTest = 1.0e38f;  // stands for 'no score' where the bits must stay finite
 
 __global__ void k_point_norms(IndexView ix, float *norm2, unsigned int *max_bits) {
   const int lane = lane_id();
@@ -105,11 +109,11 @@ __global__ __launch_bounds__(1024) void k_group_plan(GemmArgs A, Counters *ctr) 
     const int pos = A.slot_list[i];
     const unsigned long long key = A.slot_key[pos];
     const int qc = A.slot_count[pos];
-    const int64_t a = (int64_t)(key >> 32), b = (int64_t)(key & 0xffffffffull), w = b - a, wp = (w + 3) & ~(int64_t)3;
+    const int64_t a = (int64_t)(key >> 32), b = (int64_t)(key & 0xffffffffull), w = b - a;
     int g = -1;
-    // (a 128-row tile of the score matrix is addressed with 32-bit byte offsets)
-    if (qc >= kGroupMinQueries && w >= kGroupMinWindow && wp < ((int64_t)1 << 22)) {
-      const unsigned long long need = (unsigned long long)qc * (unsigned long long)wp;
+    if (qc >= kGroupMinQueries && w >= kGroupMinWindow) {
+      // entries: per query and 128-position step two blocks (one per half wave) of four floats
+      const unsigned long long need = (unsigned long long)qc * (unsigned long long)((w + 127) >> 7) * 8ull;
       const unsigned long long soff = atomicAdd(A.score_used, need);
       if (soff + need <= (unsigned long long)A.score_cap) {
         g = atomicAdd(&A.plan[P_NGROUPS], 1);
@@ -197,8 +201,7 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
   constexpr int RB = 4 * STRIDE + 16;  // bytes per staged point: hi row, lo row, 16 B so that 8 rows cover all banks
   unsigned char *Ps = smem;                                    // [128][RB]
   float *base = reinterpret_cast<float *>(smem + 128 * RB);    // [128] per staged point: |p|^2 / 0
-  float *qn = base + 128;                                      // [128] per query row: |q|^2 / 0
-  int *rid = reinterpret_cast<int *>(qn + 128);                // [128] point rows of the block being fetched
+  int *rid = reinterpret_cast<int *>(base + 128);              // [128] point rows of the block being fetched
   constexpr int s4 = STRIDE >> 2;
   constexpr int nit = s4 >> 1;  // 128 rows x s4 float4 / 256 threads (s4 is even)
   constexpr int nx = s4 >> 2;   // staging: four threads per point row (64 B contiguous), 64 rows per pass, two passes
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
     }
     const GemmGroup grp = A.groups[glo];
     const int tl = t - grp.tile0, ch = tl / grp.nqt, q0 = (tl - ch * grp.nqt) << 7;
-    const int64_t w = grp.b - grp.a, wlast = w - 1, wp = (w + 3) & ~(int64_t)3;
+    const int64_t w = grp.b - grp.a, wlast = w - 1;
     const int64_t p_begin = (int64_t)ch * kGemmPointChunk;
     const int64_t p_end = (p_begin + kGemmPointChunk < w) ? (p_begin + kGemmPointChunk) : w;
     __syncthreads();  // the previous tile is done with the staging area
@@ -246,13 +249,6 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
         *reinterpret_cast<f32x4 *>(Qs + r * DP + c) = v;
       }
       __syncthreads();
-      {
-        const int r = tid >> 1, h = tid & 1;  // two threads per query row
-        float sq = 0.f;
-        for (int c = h; c < STRIDE; c += 2) sq = fmaf(Qs[r * DP + c], Qs[r * DP + c], sq);
-        sq += __shfl_xor(sq, 1);
-        if (h == 0) qn[r] = mips ? 0.f : sq;
-      }
 #pragma unroll
       for (int s = 0; s < S; s++) {
         const float *qp = Qs + (32 * wv + col) * DP + 16 * s + 8 * half;
@@ -266,12 +262,12 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
     }
     __syncthreads();
     // The MFMA tile has the points as rows and the queries as columns: this lane holds query 32 wv + col, and register
-    // reg of tile j the window position 32 j + (reg & 3) + 8 (reg >> 2) + 4 half: four consecutive positions per
-    // 16-byte store, sixteen stores per step, all from one row pointer.
+    // reg of tile j the window position 32 j + (reg & 3) + 8 (reg >> 2) + 4 half: 64 positions of one query per step.
     const int myrow = q0 + 32 * wv + col;
     const bool live = myrow < grp.qcount;
-    float *srow = A.scores + grp.soff + (int64_t)(live ? myrow : q0) * wp + 4 * half;
-    const float qn1 = qn[32 * wv + col];
+    // this lane's entries: [query][step of the window][half] x 4 floats
+    const int64_t nsteps = (w + 127) >> 7;
+    f32x4 *erow = reinterpret_cast<f32x4 *>(A.scores + grp.soff) + ((int64_t)(live ? myrow : q0) * nsteps + (p_begin >> 7)) * 2 + half;
     // The next point block travels HBM -> registers while the MFMA loop of the current one runs (one wave per SIMD:
     // the 512-register budget is all ours), and registers -> bf16 pairs -> LDS after the barrier.  Its row numbers
     // were put in the LDS one step earlier, so no load depends on another load.
@@ -308,7 +304,7 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
         }
       }
       if (tid < 128) {
-        base[tid] = mips ? 0.f : pre_n;
+        base[tid] = (c0 + tid < p_end) ? (mips ? 0.f : pre_n) : kHuge;  // positions beyond the window never win
         rid[tid] = pre_rid;
       }
       GPROF_T(t1)
@@ -359,21 +355,30 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
         __builtin_amdgcn_sched_barrier(0);
       }
       GPROF_T(t3)
-      if (live) {
-        const bool full = c0 + 128 <= p_end;  // (wave-uniform) else: the last block of the window, which ends inside it
+      // the four smallest of this lane's 64 scores, sorted; low six mantissa bits = 16 j + reg (which position)
+      float t1 = kHuge, t2 = kHuge, t3 = kHuge, t4 = kHuge;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+      for (int j = 0; j < 4; j++)
 #pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const int p4 = 32 * j + 8 * g;  // + 4 half: in srow and below
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(base + p4 + 4 * half);
-            f32x4 o;
+        for (int g = 0; g < 4; g++) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(base + 32 * j + 8 * g + 4 * half);
 #pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = fmaf(scale, acc[j][4 * g + r], b4[r]) + qn1;
-            // rows are padded to four floats: a group of four positions is either inside the padded row or outside
-            if (full || c0 + p4 + 4 * half < wp) *reinterpret_cast<f32x4 *>(srow + c0 + p4) = o;
+          for (int r = 0; r < 4; r++) {
+            const float sc = fmaf(scale, acc[j][4 * g + r], b4[r]);
+            float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
+            float a = fminf(t1, x);
+            x = fmaxf(t1, x);
+            t1 = a;
+            a = fminf(t2, x);
+            x = fmaxf(t2, x);
+            t2 = a;
+            a = fminf(t3, x);
+            x = fmaxf(t3, x);
+            t3 = a;
+            t4 = fminf(t4, x);
           }
-      }
+        }
+      if (live) erow[(c0 - p_begin) >> 6] = f32x4{t1, t2, t3, t4};
       GPROF_T(t4)
       __syncthreads();  // every wave is done with Ps / base / rid
       GPROF_T(t5)
@@ -388,63 +393,59 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
 #undef WANN_FETCH
 }
 
-// One wave per grouped query.  The kSelect best scores live sorted in lanes 0 .. kSelect-1 (order-preserving score
-// bits in one register, window positions in another; equal scores stay in scan order = position order); a row is
-// streamed 1024 scores at a time (four 16-byte loads per lane in flight) and the few scores below the current cut
-// are inserted one by one with a ballot + one-lane shift.
+// One wave per grouped query.  Its window's blocks each handed over their four smallest scores (sorted, position in
+// the low mantissa bits).  The first three of every block are candidates, the fourth bounds everything the block kept
+// to itself.  The kSelect best candidates live sorted in lanes 0 .. kSelect-1 (score bits in one register, window
+// positions in another); candidates below the current cut are inserted one by one with a ballot + one-lane shift.
 __global__ __launch_bounds__(256) void k_select_scores(GemmArgs A) {
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   const int64_t ntq = A.plan[P_NTQ];
   for (int64_t tq = (int64_t)blockIdx.x * 4 + wv; tq < ntq; tq += (int64_t)gridDim.x * 4) {
     const GemmGroup grp = A.groups[A.tq_group[tq]];
-    const int64_t w = grp.b - grp.a, wp = (w + 3) & ~(int64_t)3;
-    const float *srow = A.scores + grp.soff + (int64_t)A.tq_local[tq] * wp;
+    const int64_t w = grp.b - grp.a, nblk = ((w + 127) >> 7) * 2;
+    const f32x4 *erow = reinterpret_cast<const f32x4 *>(A.scores + grp.soff) + (int64_t)A.tq_local[tq] * nblk;
     uint32_t top_s = 0xffffffffu, thr = 0xffffffffu;  // 0xffffffff (no float maps to it) = empty slot; thr = lane kSelect-1
     int top_p = 0, filled = 0;
-    f32x4 vn[4];  // the next 1024 scores travel while the current ones are examined
+    float bound = kHuge;
+    for (int64_t b0 = 0; b0 < nblk; b0 += 64) {
+      const int64_t blk = b0 + lane;
+      const f32x4 e = (blk < nblk) ? erow[blk] : f32x4{kHuge, kHuge, kHuge, kHuge};
+      bound = fminf(bound, e[3]);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int64_t off = j * 256 + 4 * lane;
-      vn[j] = (off < wp) ? *reinterpret_cast<const f32x4 *>(srow + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int64_t c0 = 0; c0 < wp; c0 += 1024) {
-      f32x4 v[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        v[j] = vn[j];
-        const int64_t off = c0 + 1024 + j * 256 + 4 * lane;
-        vn[j] = (off < wp) ? *reinterpret_cast<const f32x4 *>(srow + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int cmp = 0; cmp < 4; cmp++) {
-          const int64_t pos = c0 + j * 256 + 4 * lane + cmp;
-          const uint32_t key = fkey(v[j][cmp]);
-          u64 mask = ballot64(pos < w && key < thr);
-          while (mask) {
-            const int src = ctz64(mask);
-            mask &= mask - 1;
-            const uint32_t ck = (uint32_t)rdlane((int)key, src);
-            if (ck < thr) {  // wave-uniform; thr may have dropped since the ballot
-              const int p = popc64(ballot64(top_s <= ck));  // top is sorted: a prefix of the lanes
-              const int cp = (int)(c0 + j * 256 + cmp) + 4 * src;
-              const uint32_t up_s = (uint32_t)__builtin_amdgcn_update_dpp((int)top_s, (int)top_s, 0x138, 0xf, 0xf, false);
-              const int up_p = __builtin_amdgcn_update_dpp(top_p, top_p, 0x138, 0xf, 0xf, false);
-              if (lane < kSelect) {
-                top_s = (lane == p) ? ck : (lane > p ? up_s : top_s);
-                top_p = (lane == p) ? cp : (lane > p ? up_p : top_p);
-              }
-              filled += filled < kSelect;
-              thr = (uint32_t)rdlane((int)top_s, kSelect - 1);
+      for (int c = 0; c < 3; c++) {
+        const uint32_t key = fkey(e[c]);
+        u64 mask = ballot64(e[c] < kHugeTest && key < thr);
+        while (mask) {
+          const int src = ctz64(mask);
+          mask &= mask - 1;
+          const uint32_t ck = (uint32_t)rdlane((int)key, src);
+          if (ck < thr) {  // wave-uniform; thr may have dropped since the ballot
+            const int p = popc64(ballot64(top_s <= ck));  // top is sorted: a prefix of the lanes
+            // block b0 + src: step (b >> 1), half (b & 1); low bits 16 j + 4 g + r -> position 32 j + 8 g + 4 half + r
+            const uint32_t ix6 = (uint32_t)rdlane((int)__float_as_uint(e[c]), src) & 63u;
+            const int64_t bb = b0 + src;
+            const int cp = (int)((bb >> 1) * 128 + 32 * (ix6 >> 4) + 8 * ((ix6 >> 2) & 3) + 4 * (bb & 1) + (ix6 & 3));
+            const uint32_t up_s = (uint32_t)__builtin_amdgcn_update_dpp((int)top_s, (int)top_s, 0x138, 0xf, 0xf, false);
+            const int up_p = __builtin_amdgcn_update_dpp(top_p, top_p, 0x138, 0xf, 0xf, false);
+            if (lane < kSelect) {
+              top_s = (lane == p) ? ck : (lane > p ? up_s : top_s);
+              top_p = (lane == p) ? cp : (lane > p ? up_p : top_p);
             }
+            filled += filled < kSelect;
+            thr = (uint32_t)rdlane((int)top_s, kSelect - 1);
           }
         }
+      }
     }
+    for (int o = 32; o > 0; o >>= 1) bound = fminf(bound, __shfl_xor(bound, o));
     if (lane < filled) A.sel_pos[tq * kSelect + lane] = top_p;
     if (lane == 0) {
+      // every position that is not selected scores >= cut: candidates that were dropped or never inserted >= the worst
+      // selected one (once the list is full), everything else >= its block's fourth smallest
+      float cut = (filled == kSelect) ? funkey(thr) : kHuge;
+      cut = fminf(cut, bound);
       A.sel_cnt[tq] = filled;
-      A.sel_cut[tq] = (filled == kSelect && w > kSelect) ? funkey(thr) : 3.402823466e+38f;
+      A.sel_cut[tq] = (cut >= kHugeTest) ? 3.402823466e+38f : cut;
     }
   }
 }
@@ -487,15 +488,19 @@ __global__ __launch_bounds__(256) void k_rerank(GemmArgs A, Counters *ctr) {
     // the columns), fp32 accumulation of 3 d products (generous factor 8), fp32 norms and the reference's own rounding.
     const float pmax = __uint_as_float(*A.pnorm2_max_bits);
     const float cerr = 3.02f * 1.52587890625e-5f + 8.f * (float)(3 * ix.d + 8) * 5.9604645e-8f;
-    const float E = (METRIC == 1) ? cerr * sqrtf(q2 * pmax) : 2.f * cerr * (q2 + pmax);
+    // + 2^-17 relative for the six mantissa bits that carry the position (|score| <= |q||p| resp. 2 (|q|^2 + |p|^2))
+    const float cerr2 = cerr + 7.62939453125e-6f;
+    const float E = (METRIC == 1) ? cerr2 * sqrtf(q2 * pmax) : 2.f * cerr2 * (q2 + pmax);
     const int kk = cnt < A.k ? cnt : A.k;
     float dk = -3.402823466e+38f;  // k-th exact distance (the worst one that is returned)
     {
       const u64 hit = ballot64(lane < cnt && rank == kk - 1);
       if (hit) dk = __shfl(dist, ctz64(hit));
     }
-    const float cut = A.sel_cut[tq];
-    const bool proven = (cut == 3.402823466e+38f) || (dk + E < cut - E);
+    float cut = A.sel_cut[tq];
+    const bool all_taken = cut == 3.402823466e+38f;  // nothing was left out
+    if (METRIC != 1) cut += q2;                      // the L2 scores leave |q|^2 out
+    const bool proven = all_taken || (dk + E < cut - E);
     if (lane == 0) {
       A.out_cnt[ti] = kk;
       if (!proven) {

@@ -66,7 +66,8 @@ constexpr int kMaxRounds = 30;
 
 struct Workspace {
   DevBuf<Task> tasks;
-  DevBuf<int32_t> list_a, list_b, list_final, list_heavy, list_mid, list_big, list_brute, ints, out_cnt, g_table, g_table_big, qtask_cnt, next_beam;
+  DevBuf<int32_t> list_a, list_b, list_final, list_heavy, list_mid, list_big, list_brute, ints, out_cnt, g_table, g_table_big, qtask_cnt, next_beam, part_cnt, part_done;
+  DevBuf<unsigned long long> part_key;
   DevBuf<unsigned long long> out_key, g_beam;
   // wave_beam_search_big: per-slot exact seen bitmaps and filter epochs for the ordinary / follow-up launches
   // (g_table) and for the companion launch (g_table_big); a table and its epochs are zeroed together
@@ -384,8 +385,9 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   I.g_sel_pos.ensure((size_t)nq * kSelect);
   I.g_sel_cnt.ensure((size_t)nq);
   I.g_sel_cut.ensure((size_t)nq);
-  // the score matrices of all groups: nq x n floats at most, capped at 4 GiB (groups beyond that take the exact scan)
-  const size_t score_cap = (size_t)std::min<unsigned long long>((unsigned long long)nq * (unsigned long long)(I.view.n + 3), 1ull << 30);
+  // the blocks' hand-over (two blocks of four floats per query and 128 window positions), capped at 4 GiB (groups
+  // beyond that take the exact scan)
+  const size_t score_cap = (size_t)std::min<unsigned long long>((unsigned long long)nq * (unsigned long long)((I.view.n + 127) / 128) * 8ull, 1ull << 30);
   I.g_scores.ensure(score_cap);
   GemmArgs ga{};
   ga.ix = I.view;
@@ -528,6 +530,19 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     ba.out_key = W.out_key.p;
     ba.out_cnt = W.out_cnt.p;
     ba.ctr = W.ctr.p;
+    if (!getenv("WANN_NO_SPLIT_SCAN")) {
+      const size_t part_cap = (size_t)4 << 20, part_slots = 8192;  // 32 MiB of partial lists
+      const bool fresh = W.part_done.cap < part_slots;  // (a list is only split while it has far fewer entries than there are waves)
+      W.part_key.ensure(part_cap);
+      W.part_cnt.ensure(part_slots);
+      W.part_done.ensure(part_slots);
+      if (fresh) HIP_CHECK(hipMemsetAsync(W.part_done.p, 0, W.part_done.cap * sizeof(int32_t), st));  // (the kernel leaves zeros behind)
+      ba.part_key = W.part_key.p;
+      ba.part_cnt = W.part_cnt.p;
+      ba.part_done = W.part_done.p;
+      ba.part_cap = (int64_t)part_cap;
+      ba.part_slots = (int64_t)part_slots;
+    }
     int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * 4, (nq * std::min(maxt, 2) + kWavesPerBlock - 1) / kWavesPerBlock);
     if (launch_brute(ba, blocks, st)) throw HipError(std::string("k_brute: ") + launch_last_error());
   }

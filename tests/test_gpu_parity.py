@@ -605,7 +605,7 @@ def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
 @pytest.mark.parametrize("metric,sfx,d", [("mips", "FloatMips", 100), ("l2", "FloatEuclidian", 128), ("l2f", "FloatEuclidian", 96)])
 def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sfx, d):
     rng = np.random.default_rng(17)
-    nclu, per, qper = 12, 700, 40
+    nclu, per, qper = 12, 1500, 40
     n = nclu * per
     if metric == "l2":
         X = sift_like(n, d, 3)(n)
@@ -669,8 +669,8 @@ def test_dense_prefilter_slices_and_tiles(wa, gpu, monkeypatch, sfx, d, style):
     W[:300] = (100.5, 25100.5)       # 25 000 positions: eight slices of 3 200; three query tiles
     W[300:520] = (30000.5, 35000.5)  # 5 000 positions: three slices; two tiles
     W[520:560] = (-1, 1e9)           # everything
-    W[560:660] = (500.5, 700.5)      # 200 positions: one short slice
-    W[660:] = (7.5, 50.5)            # below the minimum window: exact scan
+    W[560:660] = (500.5, 1800.5)     # 1 300 positions: one short slice
+    W[660:] = (7.5, 250.5)           # below the minimum window: exact scan
     pi = getattr(wa, "PrefilterIndex" + sfx)(X, labels)
     for k in (10, 1):
         monkeypatch.delenv("WANN_NO_GEMM", raising=False)

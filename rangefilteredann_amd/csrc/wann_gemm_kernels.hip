@@ -193,7 +193,7 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t 
 // rows; every wave owns 32 query rows (A operand: bf16 pairs in registers for the whole tile) and scores them against
 // all 128 points = 1 x 4 MFMA tiles; a score row of 128 floats leaves as four 128-byte stores.
 template <int STRIDE>  // padded row length in floats: a multiple of 16, <= 128
-__global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
+__global__ __launch_bounds__(256, 2) void k_gemm_scores(GemmArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -315,29 +315,17 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
-      // B operand: the next k-step's eight ds_read_b128 are issued before the current step's twelve MFMAs
+      // B operand: eight ds_read_b128 per k-step feed twelve MFMAs; two workgroups share a CU, so the other wave of the
+      // SIMD fills the gaps (its MFMAs run under this wave's conversions and insertions, and the other way round)
       const unsigned char *pb = Ps + col * RB + 16 * half;
-      bf16x8 bh[4], bl[4], bhn[4], bln[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        bhn[j] = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB);
-        bln[j] = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB + 2 * STRIDE);
-      }
 #pragma unroll
       for (int s = 0; s < S; s++) {
         const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah[s]), a_lo = __builtin_bit_cast(bf16x8, al[s]);
-        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          bh[j] = bhn[j];
-          bl[j] = bln[j];
-        }
-        if (s + 1 < S) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            bhn[j] = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB + 32 * (s + 1));
-            bln[j] = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB + 2 * STRIDE + 32 * (s + 1));
-          }
+          bh[j] = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB + 32 * s);
+          bl[j] = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB + 2 * STRIDE + 32 * s);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], a_hi, acc[j], 0, 0, 0);
@@ -345,18 +333,10 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
         for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a_lo, acc[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a_hi, acc[j], 0, 0, 0);
-        // the reads of step s + 1 go first, the 12 MFMAs of step s run over them
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
       GPROF_T(t3)
       // the four smallest of this lane's 64 scores, sorted; low six mantissa bits = 16 j + reg (which position)
-      float t1 = kHuge, t2 = kHuge, t3 = kHuge, t4 = kHuge;
+      float m1 = kHuge, m2 = kHuge, m3 = kHuge, m4 = kHuge;
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -366,19 +346,19 @@ __global__ __launch_bounds__(256) void k_gemm_scores(GemmArgs A) {
           for (int r = 0; r < 4; r++) {
             const float sc = fmaf(scale, acc[j][4 * g + r], b4[r]);
             float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
-            float a = fminf(t1, x);
-            x = fmaxf(t1, x);
-            t1 = a;
-            a = fminf(t2, x);
-            x = fmaxf(t2, x);
-            t2 = a;
-            a = fminf(t3, x);
-            x = fmaxf(t3, x);
-            t3 = a;
-            t4 = fminf(t4, x);
+            float a = fminf(m1, x);
+            x = fmaxf(m1, x);
+            m1 = a;
+            a = fminf(m2, x);
+            x = fmaxf(m2, x);
+            m2 = a;
+            a = fminf(m3, x);
+            x = fmaxf(m3, x);
+            m3 = a;
+            m4 = fminf(m4, x);
           }
         }
-      if (live) erow[(c0 - p_begin) >> 6] = f32x4{t1, t2, t3, t4};
+      if (live) erow[(c0 - p_begin) >> 6] = f32x4{m1, m2, m3, m4};
       GPROF_T(t4)
       __syncthreads();  // every wave is done with Ps / base / rid
       GPROF_T(t5)

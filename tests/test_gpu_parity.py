@@ -686,6 +686,32 @@ def test_dense_prefilter_slices_and_tiles(wa, gpu, monkeypatch, sfx, d, style):
             assert c["gemm_unproven"] < 66, c  # the proof must hold for nearly every query on well-separated data
 
 
+@pytest.mark.parametrize("sfx,k", [("FloatEuclidian", 10), ("FloatMips", 100), ("UInt8Euclidian", 7)])
+def test_short_scan_lists_are_split(oracle, wa, gpu, monkeypatch, sfx, k):
+    """A few queries over big windows: the exact scan cuts every window into slices (one wave each, the last one merges).
+    Results must equal the oracle's and the unsplit scan's, also for k larger than a slice's share and for empty slices."""
+    rng = np.random.default_rng(23)
+    n, d, nq = 30000, 20, 5
+    if sfx.startswith("UInt8"):
+        X = rng.integers(0, 256, (n, d)).astype(np.uint8)
+        Q = rng.integers(0, 256, (nq, d)).astype(np.uint8)
+    else:
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Q = rng.standard_normal((nq, d)).astype(np.float32)
+    labels = rng.permutation(n).astype(np.float32)
+    W = np.array([[-1, 1e9], [10.5, 29000.5], [5.5, 105.5], [7.5, 9.5], [100.5, 20100.5]])
+    pi = getattr(wa, "PrefilterIndex" + sfx)(X, labels)
+    oi = getattr(oracle, "PrefilterIndex" + sfx)(X, labels)
+    monkeypatch.delenv("WANN_NO_SPLIT_SCAN", raising=False)
+    ids, dists = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
+    eids, edists = oi.batch_search(Q, W, nq, _qp(oracle, 10, 1, k))
+    ok, why = gu.same_rows(eids, edists, ids, dists, True, gu.RowContext(X, labels, Q, W, gu.metric_of(sfx)))
+    assert ok, why
+    monkeypatch.setenv("WANN_NO_SPLIT_SCAN", "1")
+    ids2, dists2 = pi.batch_search(Q, W, nq, _qp(wa, 10, 1, k))
+    assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2)
+
+
 @pytest.mark.parametrize("n,d", [(1, 4), (2, 3), (7, 5), (300, 5), (300, 17)])
 def test_tiny_shapes(oracle, wa, gpu, n, d):
     """Degenerate sizes: single-point partitions, dimensions that are not multiples of 4 / 8, windows wider

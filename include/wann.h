@@ -89,6 +89,7 @@ typedef struct {
   int64_t recovered_continuations; /* searches a follow-up launch ran because the companion launch's pollers did not
                                       serve them (launches serialised by the runtime / a profiler); 0 normally     */
   int64_t gemm_unproven; /* of gemm_queries: sent on to the exact scan because the MFMA scores could not prove the top k */
+  int64_t gemm_rescued;  /* of gemm_queries: proven after an exact scan of a few 64-position blocks of the window        */
 } wann_counters;
 
 typedef struct wann_index wann_index;

@@ -68,7 +68,9 @@ struct Counters {
   // not part of the reference's operation count)
   unsigned long long spec_searches, spec_hops, spec_dist_cmps;
   unsigned long long poll_timeouts;  // pollers that gave up waiting (serialised launches); the host re-queues what they left unserved
-  unsigned long long gemm_queries, gemm_unproven;  // dense prefilter path: queries scored on the matrix cores / of those, sent on to the exact scan
+  // dense prefilter path: queries scored on the matrix cores / of those, sent on to the exact scan / settled by an exact
+  // scan of a few 64-position blocks
+  unsigned long long gemm_queries, gemm_unproven, gemm_rescued;
 };
 
 struct RouteArgs {

@@ -47,7 +47,8 @@ struct GemmArgs {
   int64_t score_cap;  // floats; groups that do not fit any more are left to the exact scan
   int32_t *sel_pos;   // [ntq][kSelect] window-relative positions
   int32_t *sel_cnt;
-  float *sel_cut;     // every position that was not selected scores at least this (FLT_MAX: nothing was left out)
+  float *sel_cut;     // the worst selected candidate's score once kSelect are selected (FLT_MAX before that): what lost against them
+  float *sel_bound;   // the smallest fourth entry of the window's blocks (FLT_MAX: no block kept anything back)
   int32_t k;
   unsigned long long *out_key;
   int32_t *out_cnt;

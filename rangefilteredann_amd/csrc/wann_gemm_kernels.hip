@@ -422,10 +422,9 @@ __global__ __launch_bounds__(256) void k_select_scores(GemmArgs A) {
     if (lane == 0) {
       // every position that is not selected scores >= cut: candidates that were dropped or never inserted >= the worst
       // selected one (once the list is full), everything else >= its block's fourth smallest
-      float cut = (filled == kSelect) ? funkey(thr) : kHuge;
-      cut = fminf(cut, bound);
       A.sel_cnt[tq] = filled;
-      A.sel_cut[tq] = (cut >= kHugeTest) ? 3.402823466e+38f : cut;
+      A.sel_cut[tq] = (filled == kSelect) ? funkey(thr) : 3.402823466e+38f;
+      A.sel_bound[tq] = (bound >= kHugeTest) ? 3.402823466e+38f : bound;
     }
   }
 }
@@ -436,8 +435,9 @@ __global__ __launch_bounds__(256) void k_rerank(GemmArgs A, Counters *ctr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IndexView &ix = A.ix;
   const int lane = lane_id(), wv = threadIdx.x >> 6;
-  const int per_wave = wave_lds_common_bytes(ix.stride);
-  const WaveLds L = carve_wave_lds(smem + (size_t)wv * per_wave, ix.stride, 0, true);
+  const int K = A.k;
+  const int per_wave = wave_lds_common_bytes(ix.stride) + ((K + 1) & ~1) * 8;
+  const WaveLds L = carve_wave_lds(smem + (size_t)wv * per_wave, ix.stride, K, true);
   const int64_t ntq = A.plan[P_NTQ];
   for (int64_t tq = (int64_t)blockIdx.x * 4 + wv; tq < ntq; tq += (int64_t)gridDim.x * 4) {
     const GemmGroup grp = A.groups[A.tq_group[tq]];
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_rerank(GemmArgs A, Counters *ctr) {
       rank += (kl < key || (kl == key && l < lane)) ? 1 : 0;
     }
     const int ti = qrow;  // stand-alone PrefilterIndex: one task slot per query
-    if (lane < cnt && rank < A.k) A.out_key[(size_t)ti * A.k + rank] = key;
+    if (lane < cnt && rank < K) A.out_key[(size_t)ti * K + rank] = key;
     // proof: every unselected point has score >= cut, and |score - exact distance| <= E.
     // E: the products the bf16 split drops (q1 p3 + q3 p1 + q2 p2 + ...) <= 3.02 * 2^-16 |q||p| (Cauchy-Schwarz over
     // the columns), fp32 accumulation of 3 d products (generous factor 8), fp32 norms and the reference's own rounding.
@@ -471,18 +471,64 @@ __global__ __launch_bounds__(256) void k_rerank(GemmArgs A, Counters *ctr) {
     // + 2^-17 relative for the six mantissa bits that carry the position (|score| <= |q||p| resp. 2 (|q|^2 + |p|^2))
     const float cerr2 = cerr + 7.62939453125e-6f;
     const float E = (METRIC == 1) ? cerr2 * sqrtf(q2 * pmax) : 2.f * cerr2 * (q2 + pmax);
-    const int kk = cnt < A.k ? cnt : A.k;
+    const int kk = cnt < K ? cnt : K;
     float dk = -3.402823466e+38f;  // k-th exact distance (the worst one that is returned)
     {
       const u64 hit = ballot64(lane < cnt && rank == kk - 1);
       if (hit) dk = __shfl(dist, ctz64(hit));
     }
-    float cut = A.sel_cut[tq];
-    const bool all_taken = cut == 3.402823466e+38f;  // nothing was left out
-    if (METRIC != 1) cut += q2;                      // the L2 scores leave |q|^2 out
-    const bool proven = all_taken || (dk + E < cut - E);
+    // two bounds on what was not selected: candidates that lost against the selected ones (>= the worst selected), and
+    // whatever the blocks kept to themselves (>= the smallest fourth entry); FLT_MAX = no such position exists
+    const float qoff = (METRIC == 1) ? 0.f : q2;  // the L2 scores leave |q|^2 out
+    const float cut_sel = A.sel_cut[tq], cut_blk = A.sel_bound[tq];
+    const bool sel_ok = cut_sel == 3.402823466e+38f || (cnt >= K && dk + E < cut_sel + qoff - E);
+    const bool blk_ok = cut_blk == 3.402823466e+38f || (cnt >= K && dk + E < cut_blk + qoff - E);
+    bool proven = sel_ok && blk_ok;
+    int outn = kk;
+    if (!proven && sel_ok && cnt >= K) {
+      // Second chance: only some blocks' kept positions could still matter (fourth entry - E <= d_k + E; a fixed set, d_k
+      // can only improve).  Score those blocks exactly, 64 positions each, and merge; all other blocks stay proven.
+      // (Labels that correlate with the geometry put a query's best points next to each other: the same block.)
+      int m = 0, p0;
+      m = wave_merge(L.lbeam, m, K, lane < cnt, ((u64)fkey(dist) << 32) | ((u64)(uint32_t)rid << 1), L.cand_key, &p0);
+      const int64_t w = grp.b - grp.a, nblk = ((w + 127) >> 7) * 2;
+      const f32x4 *erow = reinterpret_cast<const f32x4 *>(A.scores + grp.soff) + (int64_t)A.tq_local[tq] * nblk;
+      int scanned = 0;
+      bool gave_up = false;
+      for (int64_t b0 = 0; b0 < nblk && !gave_up; b0 += 64) {
+        const float m4 = (b0 + lane < nblk) ? erow[b0 + lane][3] : kHuge;
+        u64 hide = ballot64(m4 < kHugeTest && m4 + qoff - E <= dk + E);
+        while (hide) {
+          const int64_t b = b0 + ctz64(hide);
+          hide &= hide - 1;
+          if (++scanned > 16) {
+            gave_up = true;
+            break;
+          }
+          const int64_t pos = (b >> 1) * 128 + 32 * (lane >> 4) + 8 * ((lane >> 2) & 3) + 4 * (b & 1) + (lane & 3);
+          const bool valid = pos < w;
+          const int r2 = valid ? ix.fi_sorted[grp.a + pos] : 0;
+          L.cand_id[lane] = r2;
+          WAVE_SYNC();
+          const float d2 = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, 64, 0);
+          const u64 k2 = ((u64)fkey(d2) << 32) | ((u64)(uint32_t)r2 << 1);
+          bool pass = valid;
+          if (m >= K) pass = pass && ((k2 | 1ull) < (L.lbeam[K - 1] | 1ull));
+          m = wave_merge(L.lbeam, m, K, pass, k2, L.cand_key, &p0);
+        }
+      }
+      if (!gave_up) {
+        for (int x = lane; x < m; x += 64) {
+          const u64 e = L.lbeam[x];
+          A.out_key[(size_t)ti * K + x] = (e & 0xffffffff00000000ull) | (uint32_t)((uint32_t)e >> 1);
+        }
+        outn = m;
+        proven = true;
+        if (lane == 0) atomicAdd(&ctr->gemm_rescued, 1ull);
+      }
+    }
     if (lane == 0) {
-      A.out_cnt[ti] = kk;
+      A.out_cnt[ti] = outn;
       if (!proven) {
         A.brute_list[atomicAdd(A.brute_count, 1)] = ti;
         atomicAdd(&ctr->gemm_unproven, 1ull);
@@ -551,7 +597,7 @@ int launch_select_rerank(const GemmArgs &a, Counters *ctr, void *stream) {
   const int blocks = (int)std::min<int64_t>(4096, (a.nq + 3) / 4);
   hipLaunchKernelGGL(k_select_scores, dim3(blocks), dim3(256), 0, s, a);
   if (gcheck(hipGetLastError())) return 1;
-  const size_t lds = (size_t)4 * (((a.ix.stride * 4 + 15) & ~15) + 64 * 8 + 64 * 4 + 64 * 4);
+  const size_t lds = (size_t)4 * (((a.ix.stride * 4 + 15) & ~15) + 64 * 8 + 64 * 4 + 64 * 4 + ((a.k + 1) & ~1) * 8);
   if (a.ix.metric == 1) hipLaunchKernelGGL(k_rerank<1>, dim3(blocks), dim3(256), lds, s, a, ctr);
   else hipLaunchKernelGGL(k_rerank<0>, dim3(blocks), dim3(256), lds, s, a, ctr);
   return gcheck(hipGetLastError());

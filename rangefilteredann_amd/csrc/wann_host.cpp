@@ -148,7 +148,7 @@ struct wann_index {
   DevBuf<GemmGroup> g_groups;
   DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan, g_sel_pos, g_sel_cnt;
   DevBuf<unsigned long long> g_slot_key, g_score_used;
-  DevBuf<float> g_scores, g_sel_cut;
+  DevBuf<float> g_scores, g_sel_cut, g_sel_bound;
   DevBuf<unsigned long long> g_prof;
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
@@ -385,6 +385,7 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   I.g_sel_pos.ensure((size_t)nq * kSelect);
   I.g_sel_cnt.ensure((size_t)nq);
   I.g_sel_cut.ensure((size_t)nq);
+  I.g_sel_bound.ensure((size_t)nq);
   // the blocks' hand-over (two blocks of four floats per query and 128 window positions), capped at 4 GiB (groups
   // beyond that take the exact scan)
   const size_t score_cap = (size_t)std::min<unsigned long long>((unsigned long long)nq * (unsigned long long)((I.view.n + 127) / 128) * 8ull, 1ull << 30);
@@ -414,6 +415,7 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   ga.sel_pos = I.g_sel_pos.p;
   ga.sel_cnt = I.g_sel_cnt.p;
   ga.sel_cut = I.g_sel_cut.p;
+  ga.sel_bound = I.g_sel_bound.p;
   ga.k = k;
   ga.out_key = W.out_key.p;
   ga.out_cnt = W.out_cnt.p;
@@ -842,6 +844,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.recovered_continuations = recovered;
   I.last.gemm_queries = (int64_t)W.h_ctr->gemm_queries;
   I.last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
+  I.last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");

@@ -149,6 +149,7 @@ class Index {
     d["spec_dist_cmps"] = c.spec_dist_cmps;
     d["gemm_queries"] = c.gemm_queries;
     d["gemm_unproven"] = c.gemm_unproven;
+    d["gemm_rescued"] = c.gemm_rescued;
     d["recovered_continuations"] = c.recovered_continuations;
     d["device_ms"] = c.device_ms;
     d["search_kernel_ms"] = c.search_kernel_ms;

@@ -56,4 +56,4 @@ if ref is not None:
 flops = 2.0 * nq * per * d
 print(json.dumps(dict(workload="adversarial 100x10000 d=100 MIPS, 9900 queries, window = 1 cluster", mfma_ms=out["mfma"]["ms"], mfma_qps=out["mfma"]["qps"],
                       scan_ms=out["scan"]["ms"], scan_qps=out["scan"]["qps"], mfma_equals_scan=bool(same),
-                      gemm_queries=out["mfma"]["counters"]["gemm_queries"], gemm_unproven=out["mfma"]["counters"]["gemm_unproven"], device_ms=round(out["mfma"]["counters"]["device_ms"], 3), gemm_tflops_incl_select=round(flops / out["mfma"]["ms"] / 1e9, 2), cpu_reference=cpu)))
+                      gemm_queries=out["mfma"]["counters"]["gemm_queries"], gemm_unproven=out["mfma"]["counters"]["gemm_unproven"], gemm_rescued=out["mfma"]["counters"]["gemm_rescued"], device_ms=round(out["mfma"]["counters"]["device_ms"], 3), gemm_tflops_incl_select=round(flops / out["mfma"]["ms"] / 1e9, 2), cpu_reference=cpu)))

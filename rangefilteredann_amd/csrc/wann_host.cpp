@@ -328,6 +328,7 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   // register budget: the L2 kernel holds two whole 512-B rows per lane pair in flight (2 waves/SIMD)
   int blocks_per_cu = std::min((I.view.metric == 1 ? 16 : 8) / wpb, (160 * 1024) / per_block);
   blocks_per_cu = std::max(1, blocks_per_cu);
+  if (const char *e = getenv("WANN_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(e)));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
   const int cap_bits = hash_bits(cap);
   if (force_table || cap_bytes + ((int64_t)4 << cap_bits) > pool) {  // some beam of the range keeps its filter in global memory

@@ -90,6 +90,7 @@ typedef struct {
                                       serve them (launches serialised by the runtime / a profiler); 0 normally     */
   int64_t gemm_unproven; /* of gemm_queries: sent on to the exact scan because the MFMA scores could not prove the top k */
   int64_t gemm_rescued;  /* of gemm_queries: proven after an exact scan of a few 64-position blocks of the window        */
+  int64_t deep_handoffs; /* search chains that an idle poller of the companion launch (a CU to itself) took over       */
 } wann_counters;
 
 typedef struct wann_index wann_index;

@@ -71,6 +71,7 @@ struct Counters {
   // dense prefilter path: queries scored on the matrix cores / of those, sent on to the exact scan / settled by an exact
   // scan of a few 64-position blocks
   unsigned long long gemm_queries, gemm_unproven, gemm_rescued;
+  unsigned long long deep_handoffs;  // chains handed to an idle poller of the companion launch (SearchArgs::handoff_beam)
 };
 
 struct RouteArgs {
@@ -179,6 +180,10 @@ struct SearchArgs {
   int32_t force_poll_timeout;  // test hook: pollers give up at once (exercises the host's recovery of unserved continuations)
   int32_t *dyn_count, *dyn_cursor;
   int32_t *done_count;  // ordinary tickets completed
+  // Deep chains: a task that is about to search at a beam >= handoff_beam (its third doubling level, say) is handed to an
+  // IDLE poller if there is one: the poller's search wave has a CU to itself, this wave shares its CU with seven others and
+  // would take several times as long over a chain that ends the launch (0 = off)
+  int32_t handoff_beam;
 };
 
 struct BruteArgs {

@@ -600,7 +600,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
     sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
-    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0) {
+    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0) {
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0);
       big_lds = rc.big_lds;
       a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
@@ -614,6 +614,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       a.done_count = nullptr;
       a.big_cap = 0;
       a.yield_for_big = 0;
+      a.handoff_beam = 0;
       bool with_big = false;
       SearchArgs big{};
       LaunchCfg big_lc{};
@@ -643,7 +644,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         a.yield_for_big = getenv("WANN_NO_YIELD") ? 0 : 1;
         a.big_count = W.ints.p + I_BIG_COUNT;
         if (use_pollers) {
-          a.npollers = big.npollers = 16;
+          a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : 16;
+          if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
           big.force_poll_timeout = getenv("WANN_FORCE_POLL_TIMEOUT") ? 1 : 0;  // test hook
           a.big_cap = with_big_cap;
           a.big_count = W.ints.p + I_BIG_COUNT;
@@ -704,7 +706,14 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     // the companion launch also runs when there are no levels beyond the cap yet but heavy tasks that may have to
     // double beyond it: its pollers then serve those continuations at once instead of a follow-up launch
     const bool may_continue = W.h_ints[I_RISK] > 0 && use_pollers;
-    launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue) ? big_cap : 0);
+    // A saturated launch without any of that still ends with its few longest chains (a third doubling level started at
+    // 1.5 ms of a 2.7 ms bulk runs 1.5 ms there, 0.4 ms alone): a handful of pollers, a CU each, take such chains over.
+    const int64_t deep_min = getenv("WANN_DEEP_MIN_TASKS") ? atoll(getenv("WANN_DEEP_MIN_TASKS")) : 4096;
+    int32_t deep = 0;
+    if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && !getenv("WANN_NO_DEEP") &&
+        std::max<int64_t>(4 * b0, 256) <= cap1)
+      deep = getenv("WANN_DEEP_POLLERS") ? std::max(1, atoi(getenv("WANN_DEEP_POLLERS"))) : 4;
+    launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue || deep > 0) ? big_cap : 0, deep);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
@@ -846,6 +855,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.gemm_queries = (int64_t)W.h_ctr->gemm_queries;
   I.last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
   I.last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
+  I.last.deep_handoffs = (int64_t)W.h_ctr->deep_handoffs;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");

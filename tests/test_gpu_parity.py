@@ -483,6 +483,29 @@ def _continuation_case(wa):
     return idx, Q, labels, nq
 
 
+def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
+    """A saturated launch ends with its few longest doubling chains.  With enough tasks a handful of pollers (a CU each) take
+    over chains that reach their third level; which wave runs a search must not change a row or a work counter."""
+    idx, Q, labels, nq = _continuation_case(wa)
+    handed = 0
+    for p, beam, mult in [(-3, 64, 1), (-4, 64, 2), (-2, 100, 1)]:
+        W = windows(labels, nq, p, seed=9)
+        monkeypatch.setenv("WANN_NO_DEEP", "1")
+        ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+        c = idx.counters()
+        assert c["deep_handoffs"] == 0
+        monkeypatch.delenv("WANN_NO_DEEP")
+        monkeypatch.setenv("WANN_DEEP_MIN_TASKS", "1")
+        ids2, dists2 = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+        c2 = idx.counters()
+        monkeypatch.delenv("WANN_DEEP_MIN_TASKS")
+        assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2), (p, beam, mult)
+        assert (c["beam_searches"], c["hops"], c["dist_cmps"]) == (c2["beam_searches"], c2["hops"], c2["dist_cmps"]), (c, c2)
+        assert c2["recovered_continuations"] == 0
+        handed += c2["deep_handoffs"]
+    assert handed > 0, "no chain of this test reached its third level next to an idle poller"
+
+
 def test_unserved_continuations_are_recovered(wa, gpu, monkeypatch):
     """Tasks that must double beyond the in-kernel cap after their speculative levels failed are handed to pollers of the
     companion launch.  Pollers that give up (launches serialised by the runtime or a profiler) leave them in the hand-over
@@ -558,7 +581,7 @@ def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
     class CTR(C.Structure):
         _fields_ = [(f, C.c_int64) for f in ("beam_searches", "hops", "dist_cmps", "brute_rows", "label_reads", "rounds", "spec_searches",
                                             "spec_hops", "spec_dist_cmps", "gemm_queries")] + [("device_ms", C.c_double), ("search_kernel_ms", C.c_double),
-                                                                                              ("recovered_continuations", C.c_int64), ("gemm_unproven", C.c_int64), ("gemm_rescued", C.c_int64)]
+                                                                                              ("recovered_continuations", C.c_int64), ("gemm_unproven", C.c_int64), ("gemm_rescued", C.c_int64), ("deep_handoffs", C.c_int64)]
 
     lib.wann_index_create.restype = C.c_void_p
     lib.wann_index_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double,

@@ -710,8 +710,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     // 1.5 ms of a 2.7 ms bulk runs 1.5 ms there, 0.4 ms alone): a handful of pollers, a CU each, take such chains over.
     const int64_t deep_min = getenv("WANN_DEEP_MIN_TASKS") ? atoll(getenv("WANN_DEEP_MIN_TASKS")) : 4096;
     int32_t deep = 0;
-    if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && !getenv("WANN_NO_DEEP") &&
-        std::max<int64_t>(4 * b0, 256) <= cap1)
+    // (worth a second launch only for a launch of a few milliseconds: tasks x first beam ~ hops)
+    if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && graph_n * b0 >= deep_min * 150 &&
+        !getenv("WANN_NO_DEEP") && std::max<int64_t>(4 * b0, 256) <= cap1)
       deep = getenv("WANN_DEEP_POLLERS") ? std::max(1, atoi(getenv("WANN_DEEP_POLLERS"))) : 4;
     launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue || deep > 0) ? big_cap : 0, deep);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -487,7 +487,7 @@ def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
     """A saturated launch ends with its few longest doubling chains.  With enough tasks a handful of pollers (a CU each) take
     over chains that reach their third level; which wave runs a search must not change a row or a work counter."""
     idx, Q, labels, nq = _continuation_case(wa)
-    handed = 0
+    handed = stranded = 0
     for p, beam, mult in [(-3, 64, 1), (-4, 64, 2), (-2, 100, 1)]:
         W = windows(labels, nq, p, seed=9)
         monkeypatch.setenv("WANN_NO_DEEP", "1")
@@ -503,7 +503,20 @@ def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
         assert (c["beam_searches"], c["hops"], c["dist_cmps"]) == (c2["beam_searches"], c2["hops"], c2["dist_cmps"]), (c, c2)
         assert c2["recovered_continuations"] == 0
         handed += c2["deep_handoffs"]
+        # pollers that give up at once (a profiler serialising the launches) strand what was handed to them: the host
+        # re-queues it, same rows, same counters
+        monkeypatch.setenv("WANN_DEEP_MIN_TASKS", "1")
+        monkeypatch.setenv("WANN_FORCE_POLL_TIMEOUT", "1")
+        ids3, dists3 = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+        c3 = idx.counters()
+        monkeypatch.delenv("WANN_DEEP_MIN_TASKS")
+        monkeypatch.delenv("WANN_FORCE_POLL_TIMEOUT")
+        assert np.array_equal(ids, ids3) and np.array_equal(dists, dists3), (p, beam, mult)
+        assert (c["beam_searches"], c["hops"], c["dist_cmps"]) == (c3["beam_searches"], c3["hops"], c3["dist_cmps"]), (c, c3)
+        assert c3["recovered_continuations"] == c3["deep_handoffs"], c3
+        stranded += c3["recovered_continuations"]
     assert handed > 0, "no chain of this test reached its third level next to an idle poller"
+    assert stranded > 0, "no stranded chain: the recovery of deep hand-offs did not run"
 
 
 def test_unserved_continuations_are_recovered(wa, gpu, monkeypatch):

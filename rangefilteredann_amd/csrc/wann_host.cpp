@@ -645,7 +645,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         a.big_count = W.ints.p + I_BIG_COUNT;
         if (use_pollers) {
           a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : 16;
-          if (deep_pollers > 0 || getenv("WANN_HANDOFF_ALWAYS")) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
+          if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
           big.force_poll_timeout = getenv("WANN_FORCE_POLL_TIMEOUT") ? 1 : 0;  // test hook
           a.big_cap = with_big_cap;
           a.big_count = W.ints.p + I_BIG_COUNT;

@@ -91,6 +91,7 @@ typedef struct {
   int64_t gemm_unproven; /* of gemm_queries: sent on to the exact scan because the MFMA scores could not prove the top k */
   int64_t gemm_rescued;  /* of gemm_queries: proven after an exact scan of a few 64-position blocks of the window        */
   int64_t deep_handoffs; /* search chains that an idle poller of the companion launch (a CU to itself) took over       */
+  int64_t lookaheads_used; /* levels of a chain that a poller had searched ahead by the time the chain needed them   */
 } wann_counters;
 
 typedef struct wann_index wann_index;

@@ -72,6 +72,7 @@ struct Counters {
   // scan of a few 64-position blocks
   unsigned long long gemm_queries, gemm_unproven, gemm_rescued;
   unsigned long long deep_handoffs;  // chains handed to an idle poller of the companion launch (SearchArgs::handoff_beam)
+  unsigned long long lookaheads_used;  // levels of a chain that a poller had searched ahead by the time the chain needed them
 };
 
 struct RouteArgs {
@@ -112,7 +113,7 @@ struct SearchArgs {
   IndexView ix;
   const float *queries;  // (nq, d) row-major, unpadded
   int64_t qid_base;
-  const Task *tasks;
+  Task *tasks;  // (k_search adds look-ahead tasks)
   const int32_t *list;
   const int32_t *list_count;
   const int32_t *heavy_list;   // served before `list` (may be null)
@@ -184,6 +185,10 @@ struct SearchArgs {
   // IDLE poller if there is one: the poller's search wave has a CU to itself, this wave shares its CU with seven others and
   // would take several times as long over a chain that ends the launch (0 = off)
   int32_t handoff_beam;
+  // Look-ahead searches (k_search): task slots for them come from la_count (the sub-task counter of k_route carries on),
+  // slots la_base0 + [0, ...) below la_cap; chains at beams >= la_min_beam only.  nullptr = off.
+  int32_t *la_count;
+  int32_t la_base0, la_cap, la_min_beam;
 };
 
 struct BruteArgs {

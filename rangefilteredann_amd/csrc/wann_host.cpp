@@ -615,6 +615,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       a.big_cap = 0;
       a.yield_for_big = 0;
       a.handoff_beam = 0;
+      a.la_count = nullptr;
       bool with_big = false;
       SearchArgs big{};
       LaunchCfg big_lc{};
@@ -646,6 +647,12 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         if (use_pollers) {
           a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : 16;
           if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
+          if (spec && !getenv("WANN_NO_LOOKAHEAD")) {  // look-ahead searches for chains that keep failing (k_search)
+            a.la_count = big.la_count = W.ints.p + I_SUB_COUNT;
+            a.la_base0 = big.la_base0 = (int32_t)(nq * maxt);
+            a.la_cap = big.la_cap = (int32_t)std::min<int64_t>(nq * maxt + sub_slots, INT32_MAX);
+            a.la_min_beam = big.la_min_beam = (int32_t)std::max<int64_t>(4 * first_beam, 160);
+          }
           big.force_poll_timeout = getenv("WANN_FORCE_POLL_TIMEOUT") ? 1 : 0;  // test hook
           a.big_cap = with_big_cap;
           a.big_count = W.ints.p + I_BIG_COUNT;
@@ -857,6 +864,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
   I.last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
   I.last.deep_handoffs = (int64_t)W.h_ctr->deep_handoffs;
+  I.last.lookaheads_used = (int64_t)W.h_ctr->lookaheads_used;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");

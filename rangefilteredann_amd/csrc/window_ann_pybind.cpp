@@ -151,6 +151,7 @@ class Index {
     d["gemm_unproven"] = c.gemm_unproven;
     d["gemm_rescued"] = c.gemm_rescued;
     d["deep_handoffs"] = c.deep_handoffs;
+    d["lookaheads_used"] = c.lookaheads_used;
     d["recovered_continuations"] = c.recovered_continuations;
     d["device_ms"] = c.device_ms;
     d["search_kernel_ms"] = c.search_kernel_ms;

@@ -594,7 +594,7 @@ def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
     class CTR(C.Structure):
         _fields_ = [(f, C.c_int64) for f in ("beam_searches", "hops", "dist_cmps", "brute_rows", "label_reads", "rounds", "spec_searches",
                                             "spec_hops", "spec_dist_cmps", "gemm_queries")] + [("device_ms", C.c_double), ("search_kernel_ms", C.c_double),
-                                                                                              ("recovered_continuations", C.c_int64), ("gemm_unproven", C.c_int64), ("gemm_rescued", C.c_int64), ("deep_handoffs", C.c_int64)]
+                                                                                              ("recovered_continuations", C.c_int64), ("gemm_unproven", C.c_int64), ("gemm_rescued", C.c_int64), ("deep_handoffs", C.c_int64), ("lookaheads_used", C.c_int64)]
 
     lib.wann_index_create.restype = C.c_void_p
     lib.wann_index_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double,

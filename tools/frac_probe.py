@@ -39,7 +39,7 @@ for p in [int(x) for x in args.fractions.split(",")]:
             best = c if best is None or c["device_ms"] < best["device_ms"] else best
         rec = B.recall_of(torch, gt, gcnt, ids_t)
         print(f"2^{p} beam {beam} x{mult}: recall {rec:.4f} device {best['device_ms']:.2f} ms kernel {best['search_kernel_ms']:.2f} ms rounds {best['rounds']} "
-              f"searches {best['beam_searches']} hops {best['hops']} spec_searches {best['spec_searches']} spec_hops {best['spec_hops']}", flush=True)
+              f"searches {best['beam_searches']} hops {best['hops']} spec_searches {best['spec_searches']} spec_hops {best['spec_hops']} handoffs {best.get('deep_handoffs', 0)} lookaheads_used {best.get('lookaheads_used', 0)}", flush=True)
         if os.environ.get("PROBE_COMPARE"):
             ref_rows = (ids_t.clone(), dist_t.clone()); ref_c = dict(c)
             for envs in ({"WANN_NO_BIG": "1"}, {"WANN_NO_SPEC": "1"}, {"WANN_NO_POLLERS": "1"}, {}):

@@ -176,7 +176,8 @@ struct SearchArgs {
   // failed) hands it to a "poller" -- one of the first npollers workgroups of the big launch, which after the
   // static big list waits for such items until every ordinary ticket is done -- instead of to a follow-up launch.
   int32_t npollers;
-  int32_t yield_for_big;  // ordinary launch: workgroups [0, #big items) exit at once (room for the companion launch)
+  int32_t yield_for_big;  // ordinary launch: workgroups [0, #big items) exit at once (room for the companion launch) ...
+  int32_t *big_resident;  // ... unless that many companion workgroups are running already (they count themselves here)
   int32_t *dyn_list;    // [tasks], preset to -1; a poller that takes item t leaves -2 - t (the host re-queues entries >= 0)
   int32_t force_poll_timeout;  // test hook: pollers give up at once (exercises the host's recovery of unserved continuations)
   int32_t *dyn_count, *dyn_cursor;

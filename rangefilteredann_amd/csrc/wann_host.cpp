@@ -61,7 +61,7 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
@@ -616,6 +616,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       a.yield_for_big = 0;
       a.handoff_beam = 0;
       a.la_count = nullptr;
+      a.big_resident = nullptr;
       bool with_big = false;
       SearchArgs big{};
       LaunchCfg big_lc{};
@@ -628,6 +629,10 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         big.helper = getenv("WANN_NO_HELPER") ? 0 : 1;
         big.cap_inkernel = with_big_cap;
         big.pool_bytes = (common + kSearchPoolBytes) * kWavesPerBlock - common;
+        // A companion workgroup of this size shares its CU with an ordinary one (80 KB of LDS and <= 256 registers each).
+        // The few pollers of a launch without big items (deep chains) are worth a CU each: they book its whole LDS.
+        const char *ex = getenv("WANN_BIG_EXCLUSIVE");
+        if (ex ? atoi(ex) != 0 : deep_pollers > 0) big.pool_bytes = 150 * 1024 - common;
         big.big_list = W.list_big.p;
         big.big_count = W.ints.p + I_BIG_COUNT;
         big.big_stride = W.big_stride;
@@ -643,6 +648,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         big.g_seen = W.g_seen_big.p;
         big.g_seen_words = seen_words;
         a.yield_for_big = getenv("WANN_NO_YIELD") ? 0 : 1;
+        a.big_resident = big.big_resident = W.ints.p + I_BIG_RESIDENT;
         a.big_count = W.ints.p + I_BIG_COUNT;
         if (use_pollers) {
           a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : 16;

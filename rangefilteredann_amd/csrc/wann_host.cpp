@@ -458,6 +458,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   const int64_t sub_slots = spec ? std::min<int64_t>(nq * (int64_t)maxt * 4 + 1024, (int64_t)1 << 26) : 0;
   W.ensure(nq, k, maxt, sub_slots);
   if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
+  // (look-ahead slot of a task: none.  A resolved parent is never reset by a wave before the one-wave kernel reads it.)
+  if (spec) HIP_CHECK(hipMemsetAsync(W.sub_cmps.p, 0xFF, ((size_t)nq * maxt) * sizeof(long long), st));
   I.last = wann_counters{};
   if (nq == 0) return;
   HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));

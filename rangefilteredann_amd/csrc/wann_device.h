@@ -190,6 +190,7 @@ struct SearchArgs {
   // slots la_base0 + [0, ...) below la_cap; chains at beams >= la_min_beam only.  nullptr = off.
   int32_t *la_count;
   int32_t la_base0, la_cap, la_min_beam;
+  int32_t la_found_max;  // a chain asks for a look-ahead when its last level found fewer in-window entries than this (0.4 k)
 };
 
 struct BruteArgs {

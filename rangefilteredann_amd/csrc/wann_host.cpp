@@ -660,6 +660,11 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
             a.la_base0 = big.la_base0 = (int32_t)(nq * maxt);
             a.la_cap = big.la_cap = (int32_t)std::min<int64_t>(nq * maxt + sub_slots, INT32_MAX);
             a.la_min_beam = big.la_min_beam = (int32_t)std::max<int64_t>(4 * first_beam, 160);
+            a.la_found_max = big.la_found_max = (int32_t)((2 * qp.k + 4) / 5);
+            if (getenv("WANN_LA_EAGER")) {  // test hook: every chain that fails its second level asks for one
+              a.la_min_beam = big.la_min_beam = (int32_t)(2 * first_beam);
+              a.la_found_max = big.la_found_max = (int32_t)qp.k;
+            }
           }
           big.force_poll_timeout = getenv("WANN_FORCE_POLL_TIMEOUT") ? 1 : 0;  // test hook
           a.big_cap = with_big_cap;

@@ -519,6 +519,34 @@ def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
     assert stranded > 0, "no stranded chain: the recovery of deep hand-offs did not run"
 
 
+def test_lookahead_searches_change_nothing(wa, gpu, monkeypatch):
+    """Chains that keep failing have levels searched ahead by idle pollers (and move to pollers themselves).  Batch after batch on
+    one index -- the per-task look-ahead slots are state that must not leak from one batch into the next -- rows and work
+    counters equal those of the plain sequential chains."""
+    idx, Q, labels, nq = _continuation_case(wa)
+    used = 0
+    for rep in range(2):
+        for p, beam, mult in [(-9, 10, 1), (-6, 40, 1), (-8, 20, 2), (-6, 40, 1), (-3, 64, 1)]:
+            W = windows(labels, nq, p, seed=5 + rep)
+            monkeypatch.setenv("WANN_DEEP_MIN_TASKS", "1")
+            if rep == 1:
+                monkeypatch.setenv("WANN_LA_EAGER", "1")
+            ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+            c = idx.counters()
+            monkeypatch.delenv("WANN_LA_EAGER", raising=False)
+            monkeypatch.setenv("WANN_NO_LOOKAHEAD", "1")
+            ids2, dists2 = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+            c2 = idx.counters()
+            monkeypatch.delenv("WANN_NO_LOOKAHEAD")
+            monkeypatch.delenv("WANN_DEEP_MIN_TASKS")
+            assert c2["lookaheads_used"] == 0
+            assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2), (rep, p, beam, mult)
+            assert (c["beam_searches"], c["hops"], c["dist_cmps"]) == (c2["beam_searches"], c2["hops"], c2["dist_cmps"]), (c, c2)
+            assert c["recovered_continuations"] == 0
+            used += c["lookaheads_used"]
+    assert used > 0, "no look-ahead was taken in this test"
+
+
 def test_unserved_continuations_are_recovered(wa, gpu, monkeypatch):
     """Tasks that must double beyond the in-kernel cap after their speculative levels failed are handed to pollers of the
     companion launch.  Pollers that give up (launches serialised by the runtime or a profiler) leave them in the hand-over

@@ -537,11 +537,12 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     ba.ctr = W.ctr.p;
     if (!getenv("WANN_NO_SPLIT_SCAN")) {
       const size_t part_cap = (size_t)4 << 20, part_slots = 8192;  // 32 MiB of partial lists
-      const bool fresh = W.part_done.cap < part_slots;  // (a list is only split while it has far fewer entries than there are waves)
+      // (a list is only split while it has far fewer entries than there are waves)
       W.part_key.ensure(part_cap);
       W.part_cnt.ensure(part_slots);
       W.part_done.ensure(part_slots);
-      if (fresh) HIP_CHECK(hipMemsetAsync(W.part_done.p, 0, W.part_done.cap * sizeof(int32_t), st));  // (the kernel leaves zeros behind)
+      // the kernel leaves zeros behind -- unless a batch ended in an error: 32 KB per batch buy that certainty
+      HIP_CHECK(hipMemsetAsync(W.part_done.p, 0, W.part_done.cap * sizeof(int32_t), st));
       ba.part_key = W.part_key.p;
       ba.part_cnt = W.part_cnt.p;
       ba.part_done = W.part_done.p;

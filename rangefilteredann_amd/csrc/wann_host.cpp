@@ -816,8 +816,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       HIP_CHECK(hipMemcpy(h.data(), d_trace.p, h.size() * 8, hipMemcpyDeviceToHost));
       if (FILE *f = fopen(trace_path, "w")) {
         for (long long i = 0; i < std::min<long long>(h[0], (long long)trace_cap); i++)
-          fprintf(f, "%lld %lld %lld %lld %lld %lld\n", h[1 + 4 * i] & 0xffffffffll, (h[1 + 4 * i] >> 40) & 1, (h[1 + 4 * i] >> 41) & 1, h[2 + 4 * i],
-                  h[3 + 4 * i], h[4 + 4 * i]);
+          fprintf(f, "%lld %lld %lld %lld %lld %lld %lld %lld\n", h[1 + 4 * i] & 0xffffffffll, (h[1 + 4 * i] >> 40) & 1, (h[1 + 4 * i] >> 41) & 1,
+                  h[2 + 4 * i] & 0xffffffffll, h[3 + 4 * i], h[4 + 4 * i], (h[1 + 4 * i] >> 32) & 0xff, h[2 + 4 * i] >> 32);  // + found, parent
         fclose(f);
       }
     }

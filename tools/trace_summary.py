@@ -1,6 +1,6 @@
-"""Dev tool: summarise a WANN_TASK_TRACE file (task sub big beam start end; 100 MHz ticks)."""
+"""Dev tool: summarise a WANN_TASK_TRACE file (task sub big beam start end found parent; 100 MHz ticks)."""
 import sys, numpy as np
-a = np.loadtxt(sys.argv[1], dtype=np.int64).reshape(-1, 6)
+a = np.loadtxt(sys.argv[1], dtype=np.int64, ndmin=2)
 t0 = a[:, 4].min(); st = (a[:, 4] - t0) / 1e5; en = (a[:, 5] - t0) / 1e5   # ms
 print(f"{len(a)} searches, span {en.max():.2f} ms")
 for b in sorted(set(a[:, 3])):

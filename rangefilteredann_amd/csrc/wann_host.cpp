@@ -668,7 +668,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
             }
           }
           big.force_poll_timeout = getenv("WANN_FORCE_POLL_TIMEOUT") ? 1 : 0;  // test hook
-          a.big_cap = with_big_cap;
+          a.big_cap = big.big_cap = with_big_cap;  // (the companion's own chains ask for look-aheads too)
           a.big_count = W.ints.p + I_BIG_COUNT;
           a.dyn_list = big.dyn_list = W.list_big.p + 2 * (size_t)W.big_stride;
           a.dyn_count = big.dyn_count = W.ints.p + I_DYN_COUNT;

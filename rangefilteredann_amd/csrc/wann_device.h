@@ -190,6 +190,8 @@ struct SearchArgs {
   // slots la_base0 + [0, ...) below la_cap; chains at beams >= la_min_beam only.  nullptr = off.
   int32_t *la_count;
   int32_t la_base0, la_cap, la_min_beam;
+  int32_t scan_tasks, scan_min_top;  // idle pollers scan task slots [0, scan_tasks) for speculating tasks that will need the
+                                     // level after their highest one (highest beam >= scan_min_top); 0 = no scan
   int32_t la_found_max;  // a chain asks for a look-ahead when its last level found fewer in-window entries than this (0.4 k)
 };
 

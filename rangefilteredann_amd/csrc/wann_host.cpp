@@ -460,6 +460,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
   // (look-ahead slot of a task: none.  A resolved parent is never reset by a wave before the one-wave kernel reads it.)
   if (spec) HIP_CHECK(hipMemsetAsync(W.sub_cmps.p, 0xFF, ((size_t)nq * maxt) * sizeof(long long), st));
+  // (a sub-task slot's count is -1 until its search has finished: what the pollers' scan goes by)
+  if (spec) HIP_CHECK(hipMemsetAsync(W.out_cnt.p + (size_t)nq * maxt, 0xFF, (size_t)sub_slots * sizeof(int32_t), st));
   I.last = wann_counters{};
   if (nq == 0) return;
   HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
@@ -603,6 +605,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
     sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
+    const bool scan_on = spec && getenv("WANN_SCAN") && atoi(getenv("WANN_SCAN")) != 0 && !getenv("WANN_NO_LOOKAHEAD");
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0) {
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0);
       big_lds = rc.big_lds;
@@ -654,7 +657,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         a.big_resident = big.big_resident = W.ints.p + I_BIG_RESIDENT;
         a.big_count = W.ints.p + I_BIG_COUNT;
         if (use_pollers) {
-          a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : 16;
+          // (companion workgroups share their CUs: pollers are cheap; with the scan on, idle ones look for chains that need a look-ahead)
+          a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : (getenv("WANN_POLLERS") ? std::max(1, atoi(getenv("WANN_POLLERS"))) : (scan_on ? 32 : 16));
           if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
           if (spec && !getenv("WANN_NO_LOOKAHEAD")) {  // look-ahead searches for chains that keep failing (k_search)
             a.la_count = big.la_count = W.ints.p + I_SUB_COUNT;
@@ -662,6 +666,10 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
             a.la_cap = big.la_cap = (int32_t)std::min<int64_t>(nq * maxt + sub_slots, INT32_MAX);
             a.la_min_beam = big.la_min_beam = (int32_t)std::max<int64_t>(4 * first_beam, 160);
             a.la_found_max = big.la_found_max = (int32_t)((2 * qp.k + 4) / 5);
+            if (deep_pollers == 0 && scan_on) {  // (companion mode: there are speculating tasks)
+              big.scan_tasks = (int32_t)std::min<int64_t>(nq * maxt, INT32_MAX);
+              big.scan_min_top = getenv("WANN_SCAN_MIN_TOP") ? atoi(getenv("WANN_SCAN_MIN_TOP")) : 2560;
+            }
             if (getenv("WANN_LA_EAGER")) {  // test hook: every chain that fails its second level asks for one
               a.la_min_beam = big.la_min_beam = (int32_t)(2 * first_beam);
               a.la_found_max = big.la_found_max = (int32_t)qp.k;

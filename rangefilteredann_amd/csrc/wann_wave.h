@@ -1012,7 +1012,9 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
                                                      int64_t qid, int64_t limit, int degree_limit, int32_t *mini,
                                                      uint32_t mini_mask, int &m_out, long long &nvis_out,
                                                      long long &ncmp_out, unsigned long long *prof = nullptr,
-                                                     PrefetchBox *box = nullptr, int part_index = 0) {
+                                                     PrefetchBox *box = nullptr, int part_index = 0,
+                                                     const int32_t *abort_flag = nullptr) {
+  // abort_flag: a look-ahead search (k_search) that its chain has withdrawn (*abort_flag == 2) stops at the next check
   prof = WANN_PROF_PTR(prof);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
@@ -1117,6 +1119,11 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     //      entry of the LDS beam and the first unvisited entry of the delta list
     const u64 du = ballot64(lane < D && !(dk & 1ull));
     if ((pmk == ~0ull && du == 0) || nvis >= lim) break;
+    if (abort_flag && (nvis & 31) == 0) {
+      int ab = 0;
+      if (lane == 0) ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (uni(ab) == 2) break;
+    }
     int cur = 0;
     bool from_delta = false;
     if (du) {

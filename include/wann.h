@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WANN_ABI_VERSION 2
+#define WANN_ABI_VERSION 3
 
 enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP = 3, WANN_ERR_IO = 4,
        WANN_ERR_UNSUPPORTED = 5 };
@@ -92,6 +92,14 @@ typedef struct {
   int64_t gemm_rescued;  /* of gemm_queries: proven after an exact scan of a few 64-position blocks of the window        */
   int64_t deep_handoffs; /* search chains that an idle poller of the companion launch (a CU to itself) took over       */
   int64_t lookaheads_used; /* levels of a chain that a poller had searched ahead by the time the chain needed them   */
+  /* ABI 3: the one-wave kernel (long searches: a search wave fed by three scoring helper waves) */
+  int64_t big_searches;    /* beam searches that ran there (speculated ones included)                                  */
+  int64_t big_hops;        /* their hops                                                                               */
+  int64_t packet_hops;     /* of big_hops: adjacency row and distances came from a helper wave's packet                */
+  int64_t own_scorings;    /* of big_hops: the search wave had to score at least one neighbour itself                  */
+  int64_t prefetched_hops; /* of big_hops: packet and filter probes were fetched during the previous hop               */
+  int64_t poll_timeouts;   /* pollers of the companion launch that gave up waiting (serialised launches)               */
+  int64_t lookaheads_issued; /* look-ahead searches handed to waiting pollers (lookaheads_used of them were needed)    */
 } wann_counters;
 
 typedef struct wann_index wann_index;

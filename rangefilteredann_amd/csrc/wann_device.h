@@ -73,6 +73,9 @@ struct Counters {
   unsigned long long gemm_queries, gemm_unproven, gemm_rescued;
   unsigned long long deep_handoffs;  // chains handed to an idle poller of the companion launch (SearchArgs::handoff_beam)
   unsigned long long lookaheads_used;  // levels of a chain that a poller had searched ahead by the time the chain needed them
+  // one-wave kernel (wave_beam_search_big): searches, hops, hops served by a helper packet, hops with scoring in the search wave
+  unsigned long long big_searches, big_hops, packet_hops, own_scorings, prefetched_hops;
+  unsigned long long lookaheads_issued;  // look-ahead searches handed to pollers (used or not)
 };
 
 struct RouteArgs {
@@ -145,7 +148,8 @@ struct SearchArgs {
   int32_t old_general;          // dev / test: the first-generation general core (wave_beam_search) instead
   int32_t cut_k;                // raw mode, unfiltered VamanaIndex queries: QueryParams::k and ::cut of beamSearch.h:159-167
   double cut;                   //   (0: no cut step -- the post-filter path never takes it)
-  int32_t helper;               // one-wave kernel: a second wave per workgroup prefetches ahead of the search (prefetch_helper)
+  int32_t helper;               // one-wave kernel: number of helper waves per workgroup (0 or kHelpers) that prepare row + distance
+                                // packets ahead of the search (score_helper)
   unsigned long long *g_beam;   // per wave slot beam, g_beam_cap entries each (or null)
   int64_t g_beam_cap;
   Counters *ctr;
@@ -181,6 +185,7 @@ struct SearchArgs {
   int32_t *dyn_list;    // [tasks], preset to -1; a poller that takes item t leaves -2 - t (the host re-queues entries >= 0)
   int32_t force_poll_timeout;  // test hook: pollers give up at once (exercises the host's recovery of unserved continuations)
   int32_t *dyn_count, *dyn_cursor;
+  int32_t *poll_waiting;  // pollers inside their wait loop right now
   int32_t *done_count;  // ordinary tickets completed
   // Deep chains: a task that is about to search at a beam >= handoff_beam (its third doubling level, say) is handed to an
   // IDLE poller if there is one: the poller's search wave has a CU to itself, this wave shares its CU with seven others and
@@ -246,5 +251,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxLdsBits = 12;       // build kernels: seen-filters up to 2^12 entries live in the LDS
 constexpr int kSearchPoolBytes = 18432;  // k_search per-wave LDS pool: beam + filter of beams <= 128 (2^12 slots), beam alone <= 2304
 constexpr int kInKernelBeamCap = 1280;   // largest beam the first (in-kernel doubling) launch runs
+// one-wave kernel: helper waves per search wave (wann_wave.h score_helper) and the bytes of their LDS mailbox (ScoreBox,
+// at the end of the search wave's pool)
+constexpr int kHelpers = 3;
+constexpr int kScoreBoxBytes = 9600;
 
 }  // namespace wann

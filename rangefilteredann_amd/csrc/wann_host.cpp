@@ -61,7 +61,7 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_POLL_WAITING = 146, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
@@ -313,16 +313,26 @@ struct RoundCfg {
 // The four-wave kernel holds the register-resident cores and the second-generation general core only (256 registers per
 // wave); everything else -- beams whose LDS beam exceeds the four-wave pool, the first-generation cores behind the test
 // switches -- runs in the one-wave-per-workgroup kernel (big_lds).  force_table: a global seen-filter even if the LDS would do.
-RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false) {
+// legacy: the one-wave kernel that holds the first-generation cores (k_search<., 2>: dev switches, the cut step); it is also
+// what a beam that does not fit the LDS next to the helper waves' mailbox gets.  The production one-wave kernel
+// (k_search<., 1>) always keeps its seen-filter in global memory.
+RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false,
+                    bool legacy = false) {
   RoundCfg rc{};
   const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
   if (cap_bytes > kSearchPoolBytes) big_lds = true;
   const int wpb = big_lds ? 1 : kWavesPerBlock;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
+  if (big_lds && !legacy && cap_bytes + 4096 + kScoreBoxBytes > 150 * 1024 - common) legacy = true;
+  const int box_bytes = (big_lds && !legacy) ? kScoreBoxBytes : 0;
+  if (big_lds && !legacy) force_table = true;
   int pool = kSearchPoolBytes;
-  // (one-wave kernel: + the clash-detection scratch and the prefetch helper's mailbox beside the largest beam)
-  if (big_lds) pool = (int)std::min<int64_t>(std::max<int64_t>(cap_bytes + 4096 + 64, kSearchPoolBytes), 150 * 1024 - common);
+  // (one-wave kernels: + the clash-detection scratch beside the largest beam; production kernel: + the helper waves' mailbox
+  // at the end of the pool -- the kernel takes kScoreBoxBytes off whenever it runs with helpers, so the decisions below use
+  // what is left)
+  if (big_lds) pool = (int)std::min<int64_t>(std::max<int64_t>(cap_bytes + 4096, kSearchPoolBytes) + box_bytes, 150 * 1024 - common);
   rc.pool_bytes = pool;
+  const int usable = pool - box_bytes;
   const int per_block = (common + pool) * wpb;
   if (per_block > 160 * 1024) throw std::runtime_error("beam-search LDS footprint exceeds 160 KiB");
   // register budget: the L2 kernel holds two whole 512-B rows per lane pair in flight (2 waves/SIMD)
@@ -331,18 +341,18 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   if (const char *e = getenv("WANN_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(e)));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
   const int cap_bits = hash_bits(cap);
-  if (force_table || cap_bytes + ((int64_t)4 << cap_bits) > pool) {  // some beam of the range keeps its filter in global memory
+  if (force_table || cap_bytes + ((int64_t)4 << cap_bits) > usable) {  // some beam of the range keeps its filter in global memory
     rc.table_bits = cap_bits;
     int64_t per_slot = (int64_t)4 << cap_bits;
     int64_t max_slots = std::max<int64_t>(wpb, ((int64_t)16 << 30) / per_slot);
     blocks = std::min(blocks, max_slots / wpb);
   }
-  if (cap_bytes > pool) rc.beam_cap = (cap + 1) & ~(int64_t)1;
+  if (cap_bytes > usable) rc.beam_cap = (cap + 1) & ~(int64_t)1;
   (void)first_beam;
   blocks = std::min<int64_t>(blocks, (work_items + wpb - 1) / wpb);
   rc.lc.blocks = (int)std::max<int64_t>(blocks, 1);
   rc.lc.waves_per_block = wpb;
-  rc.lc.big = big_lds ? 1 : 0;
+  rc.lc.big = big_lds ? (legacy ? 2 : 1) : 0;
   rc.big_lds = big_lds;
   rc.slots = rc.lc.blocks * wpb;
   return rc;
@@ -387,9 +397,10 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   I.g_sel_cnt.ensure((size_t)nq);
   I.g_sel_cut.ensure((size_t)nq);
   I.g_sel_bound.ensure((size_t)nq);
-  // the blocks' hand-over (two blocks of four floats per query and 128 window positions), capped at 4 GiB (groups
+  // the blocks' hand-over (two blocks of four floats per query and 128 window positions), capped at 256 MiB (groups
   // beyond that take the exact scan)
-  const size_t score_cap = (size_t)std::min<unsigned long long>((unsigned long long)nq * (unsigned long long)((I.view.n + 127) / 128) * 8ull, 1ull << 30);
+  // (a window group uses queries x its own blocks x 8 floats: 25 MB for the adversarial batch; what does not fit the cap takes the exact scan)
+  const size_t score_cap = (size_t)std::min<unsigned long long>((unsigned long long)nq * (unsigned long long)((I.view.n + 127) / 128) * 8ull, 64ull << 20);
   I.g_scores.ensure(score_cap);
   GemmArgs ga{};
   ga.ix = I.view;
@@ -605,12 +616,13 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
     sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
-    const bool scan_on = spec && getenv("WANN_SCAN") && atoi(getenv("WANN_SCAN")) != 0 && !getenv("WANN_NO_LOOKAHEAD");
+    // (idle pollers look for chains that will outgrow their speculated levels: on unless WANN_SCAN=0)
+    const bool scan_on = spec && !(getenv("WANN_SCAN") && atoi(getenv("WANN_SCAN")) == 0) && !getenv("WANN_NO_LOOKAHEAD");
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0) {
-      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0);
+      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0, a.old_general != 0);
       big_lds = rc.big_lds;
       a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
-      a.helper = (big_lds && !getenv("WANN_NO_HELPER")) ? 1 : 0;
+      a.helper = (rc.lc.big == 1 && !getenv("WANN_NO_HELPER")) ? kHelpers : 0;
       a.B = (int32_t)first_beam;
       a.cap_inkernel = (int32_t)cap;
       a.pool_bytes = rc.pool_bytes;
@@ -632,7 +644,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         with_big = true;
         const int common = search_lds_bytes_per_wave(I.view.stride, 0);
         big = a;
-        big.helper = getenv("WANN_NO_HELPER") ? 0 : 1;
+        big_lc.big = a.old_general ? 2 : 1;  // (WANN_OLD_GENERAL: the first-generation core also for the companion's searches)
+        big.helper = (big_lc.big == 2 || getenv("WANN_NO_HELPER")) ? 0 : kHelpers;
         big.cap_inkernel = with_big_cap;
         big.pool_bytes = (common + kSearchPoolBytes) * kWavesPerBlock - common;
         // A companion workgroup of this size shares its CU with an ordinary one (80 KB of LDS and <= 256 registers each).
@@ -647,7 +660,6 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         big.g_table_bits = hash_bits(with_big_cap);
         big_lc.blocks = I.num_cus;
         big_lc.waves_per_block = 1;
-        big_lc.big = 1;
         ensure_filter_scratch(W.g_table_big, W.g_epoch_big, W.g_seen_big, W.g_table_big_layout, big_lc.blocks, big.g_table_bits, seen_words, st);
         big.g_table = W.g_table_big.p;
         big.g_epoch = W.g_epoch_big.p;
@@ -681,6 +693,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
           a.dyn_list = big.dyn_list = W.list_big.p + 2 * (size_t)W.big_stride;
           a.dyn_count = big.dyn_count = W.ints.p + I_DYN_COUNT;
           a.dyn_cursor = big.dyn_cursor = W.ints.p + I_DYN_CURSOR;
+          a.poll_waiting = big.poll_waiting = W.ints.p + I_POLL_WAITING;
           a.done_count = big.done_count = W.ints.p + I_DONE;
           HIP_CHECK(hipMemsetAsync(a.dyn_list, 0xFF, (size_t)W.big_stride * sizeof(int32_t), st));
         }
@@ -688,7 +701,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       a.g_epoch = nullptr;
       a.g_seen = nullptr;
       if (rc.table_bits) {
-        if (big_lds) {  // second-generation core: tagged filter entries + exact seen bitmaps
+        if (rc.lc.big == 1) {  // second-generation core: tagged filter entries + exact seen bitmaps
           ensure_filter_scratch(W.g_table_f, W.g_epoch_f, W.g_seen_f, W.g_table_f_layout, rc.slots, rc.table_bits, seen_words, st);
           a.g_table = W.g_table_f.p;
           a.g_epoch = W.g_epoch_f.p;
@@ -756,7 +769,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       HIP_CHECK(hipMemcpyAsync(dl.data(), W.list_big.p + 2 * (size_t)W.big_stride, (size_t)dyn_n * 4, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       for (int32_t t : dl)
-        if (t >= 0) unserved.push_back(t);
+        if (t >= 0 && (int64_t)t < nq * (int64_t)maxt) unserved.push_back(t);  // (entries beyond: look-aheads nobody picked up -- their chains search on)
       if (!unserved.empty()) {
         HIP_CHECK(hipMemcpyAsync(W.list_b.p + next_n, unserved.data(), unserved.size() * 4, hipMemcpyHostToDevice, st));
         next_n += (int)unserved.size();
@@ -887,6 +900,13 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
   I.last.deep_handoffs = (int64_t)W.h_ctr->deep_handoffs;
   I.last.lookaheads_used = (int64_t)W.h_ctr->lookaheads_used;
+  I.last.big_searches = (int64_t)W.h_ctr->big_searches;
+  I.last.big_hops = (int64_t)W.h_ctr->big_hops;
+  I.last.packet_hops = (int64_t)W.h_ctr->packet_hops;
+  I.last.own_scorings = (int64_t)W.h_ctr->own_scorings;
+  I.last.prefetched_hops = (int64_t)W.h_ctr->prefetched_hops;
+  I.last.poll_timeouts = (int64_t)W.h_ctr->poll_timeouts;
+  I.last.lookaheads_issued = (int64_t)W.h_ctr->lookaheads_issued;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");
@@ -1127,6 +1147,15 @@ struct RawGraph {
   DevBuf<PartDesc> d_parts;
   int64_t n = 0, d = 0, subset_n = 0;
   int32_t maxdeg = 0;
+  // per-call buffers, kept across calls (a VamanaIndex answers batch after batch)
+  DevBuf<float> d_q, d_rd;
+  DevBuf<int32_t> d_list, d_ints, d_rid, d_rsz, g_table, g_epoch;
+  DevBuf<Task> d_tasks;
+  DevBuf<long long> d_hops, d_cmps, d_qids;
+  DevBuf<Counters> d_ctr;
+  DevBuf<unsigned long long> g_beam, d_prof;
+  DevBuf<uint32_t> g_seen;
+  int64_t layout = -1;
   // points: (n, d) rows of `dtype` elements (float32, or uint8 / int8 bytes: stored as byte rows)
   void load(int device, int metric, const void *points, int64_t n_, int64_t d_, const int32_t *graph_rows, int64_t maxdeg_,
             int64_t subset_start, int64_t subset_n_, int dtype = WANN_DTYPE_F32) {
@@ -1170,11 +1199,6 @@ struct RawGraph {
   void search(const float *queries, int64_t nq, const int64_t *query_ids, int64_t beam, int64_t limit, int64_t degree_limit,
               int64_t cut_k, double cut, int32_t *out_ids, float *out_dists, int32_t *out_sizes, int64_t *out_hops, int64_t *out_dist_cmps) {
     HIP_CHECK(hipSetDevice(I.device));
-    DevBuf<float> d_q, d_rd;
-    DevBuf<int32_t> d_list, d_ints, d_rid, d_rsz;
-    DevBuf<Task> d_tasks;
-    DevBuf<long long> d_hops, d_cmps, d_qids;
-    DevBuf<Counters> d_ctr;
     std::vector<float> qv(queries, queries + (size_t)nq * d);
     d_q.upload(qv);
     std::vector<Task> tasks((size_t)nq);
@@ -1200,9 +1224,7 @@ struct RawGraph {
     const bool with_cut = cut_k > 0;
     const bool old_general = getenv("WANN_OLD_GENERAL") != nullptr || with_cut, force_general = getenv("WANN_FORCE_GENERAL") != nullptr || with_cut;
     // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
-    RoundCfg rc = config_for(I, beam, beam, nq, getenv("WANN_RAW_BIG_LDS") != nullptr || old_general, force_general);
-    DevBuf<int32_t> g_table;
-    DevBuf<unsigned long long> g_beam;
+    RoundCfg rc = config_for(I, beam, beam, nq, getenv("WANN_RAW_BIG_LDS") != nullptr || old_general, force_general, old_general);
     SearchArgs sa{};
     sa.ix = I.view;
     sa.queries = d_q.p;
@@ -1229,11 +1251,8 @@ struct RawGraph {
     sa.raw_qids = d_qids.p;
     sa.cut_k = (int32_t)cut_k;
     sa.cut = cut;
-    DevBuf<int32_t> g_epoch;
-    DevBuf<uint32_t> g_seen;
-    int64_t layout = -1;
     sa.old_general = old_general ? 1 : 0;
-    sa.helper = (rc.big_lds && !getenv("WANN_NO_HELPER") && !with_cut) ? 1 : 0;
+    sa.helper = (rc.lc.big == 1 && !getenv("WANN_NO_HELPER")) ? kHelpers : 0;
     if (rc.table_bits) {
       const int64_t seen_words = ((subset_n + 127) / 128) * 4;
       ensure_filter_scratch(g_table, g_epoch, g_seen, layout, rc.slots, rc.table_bits, seen_words, nullptr);
@@ -1248,21 +1267,36 @@ struct RawGraph {
       g_beam.ensure((size_t)rc.slots * sa.g_beam_cap);
       sa.g_beam = g_beam.p;
     }
-    DevBuf<unsigned long long> d_prof;
     const bool prof = getenv("WANN_PROFILE_PHASES") != nullptr;
     if (prof) {
-      d_prof.ensure(8);
-      HIP_CHECK(hipMemset(d_prof.p, 0, 8 * sizeof(unsigned long long)));
+      d_prof.ensure(16);
+      HIP_CHECK(hipMemset(d_prof.p, 0, 16 * sizeof(unsigned long long)));
       sa.prof = d_prof.p;
     }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool verbose = getenv("WANN_VERBOSE") != nullptr;
+    if (verbose) {
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      HIP_CHECK(hipEventRecord(e0, nullptr));
+    }
     if (launch_search(sa, rc.lc, nullptr)) throw HipError(std::string("k_search: ") + launch_last_error());
+    if (verbose) HIP_CHECK(hipEventRecord(e1, nullptr));
     HIP_CHECK(hipDeviceSynchronize());
+    if (verbose) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      fprintf(stderr, "[wann raw] beam %ld nq %ld kernel kind %d blocks %d: %.3f ms\n", (long)beam, (long)nq, rc.lc.big, rc.lc.blocks, ms);
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
     if (prof) {
-      unsigned long long h[8];
+      unsigned long long h[16];
       HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof h, hipMemcpyDeviceToHost));
       fprintf(stderr, "[wann phases] beam=%ld nq=%ld cycles: row %llu filter %llu dist %llu merge %llu next %llu (built with make PROFILE=1?)\n", (long)beam,
               (long)nq, h[0], h[1], h[2], h[3], h[4]);
-      fprintf(stderr, "[wann waits] cycles: row load %llu, filter + seen probes %llu, scoring routine %llu\n", h[5], h[6], h[7]);
+      fprintf(stderr, "[wann phases 5..9] %llu %llu %llu %llu %llu (second-generation core: select / row+probes / next+requests / slot test / filter / "
+                      "next packet / distances / delta insert / truncation)\n", h[5], h[6], h[7], h[8], h[9]);
     }
     HIP_CHECK(hipMemcpy(out_ids, d_rid.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_dists, d_rd.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
@@ -1406,7 +1440,9 @@ int wann_vamana_build_file(int metric, int dtype, const char *data_path, const c
     if (n <= 0 || d <= 0) return fail(WANN_ERR_INVALID, "empty point file");
 
     // one Vamana graph over the points in file order = the stand-alone post-filter index's graph
-    // (knn_index::build_index, vamana/index.h:123-313, BuildParams(R, L, alpha) types.h:94)
+    // (knn_index::build_index, vamana/index.h:123-313, BuildParams(R, L, alpha) types.h:94).  The labels only have to be
+    // distinct and increasing for the builder to keep file order: float(i) is that below 2^24 points
+    if (n > ((int64_t)1 << 24)) return fail(WANN_ERR_UNSUPPORTED, "wann_vamana_build_file: more than 2^24 points are not supported");
     std::vector<float> labels((size_t)n);
     for (int64_t i = 0; i < n; i++) labels[(size_t)i] = (float)i;
     wann_build_params bp{max_degree, limit, alpha, ""};

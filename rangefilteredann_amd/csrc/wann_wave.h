@@ -35,6 +35,16 @@ __device__ __forceinline__ u64 rdlane64(u64 v, int l) {
   uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
   return ((u64)hi << 32) | lo;
 }
+// a wave-uniform 64-bit value the compiler can not prove uniform (it came from a vector or atomic load): into scalar registers
+__device__ __forceinline__ long long uni64(long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)v >> 32));
+  return (long long)(((u64)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ T *uniptr(T *p) {
+  return reinterpret_cast<T *>(uni64((long long)reinterpret_cast<uintptr_t>(p)));
+}
 __device__ __forceinline__ int ctz64(u64 m) { return __builtin_ctzll(m); }
 __device__ __forceinline__ int popc64(u64 m) { return __builtin_popcountll(m); }
 __device__ __forceinline__ u64 lanemask_lt() { return ((u64)1 << lane_id()) - 1; }
@@ -840,109 +850,116 @@ __device__ __forceinline__ u64 wave_shr1(u64 v) {  // lane i receives lane i-1's
 }
 
 // --------------------------------------------------------------------------------------------
-// Prefetch helper wave (one-wave-per-search kernel only).  A long search is one chain of dependent hops, each of
-// which is three dependent memory round trips (adjacency row -> filter / seen-set probes -> vectors).  The search
-// wave publishes, after every hop, the nodes it is likely to visit next (the first unvisited entries of its beam);
-// a second wave of the same workgroup walks exactly that chain for those nodes AHEAD of the search -- row, then
-// the filter slots and seen-set words of the row's neighbours, then the vector lines of the neighbours that are
-// not scored yet -- and throws the data away: its only effect is that the search wave's own loads hit the L2.
-// No data flows back, so the helper cannot change a result; a wrong or late prediction costs a cache miss.
+// Scoring helper waves (one-wave-per-search kernel only).  A long search is one chain of dependent hops, each of
+// which is three dependent memory round trips (adjacency row -> filter / seen-set probes -> vectors) plus the
+// distance arithmetic.  Which node a hop visits is almost always known several hops ahead (the next unvisited
+// entries of the beam), and row, filter slots and distances of a node are PURE functions of (query, node).  So the
+// search wave REQUESTS the nodes it expects to visit and three helper waves of the same workgroup prepare a PACKET
+// per node in the LDS: the node's adjacency row, its neighbours' filter slots, whether two of them share a slot, and
+// the distances of the neighbours that are not in the exact seen set yet (they also touch the filter slots, so the
+// search wave's own probes hit the L2).  The search wave takes all that from the packet; everything that has
+// sequential semantics -- the lossy filter, the seen set, cutoff, union -- stays in the search wave, in program
+// order.  A packet that is missing, late or lacks a distance costs the search wave the work it would have done
+// anyway; a helper can not change a result.
+// Request i (a node) is served by helper i % kHelpers into packet slot i % kPkSlots; the search wave keeps the
+// slot -> node map in a register, so finding a packet costs no memory access.
 // --------------------------------------------------------------------------------------------
-struct PrefetchBox {   // LDS mailbox, written by the search wave
-  int32_t gen;         // < 0: the kernel is ending; 0: no search is running; > 0: generation of the running search
-  int32_t seq;         // bumped after every update of pred[]
-  int32_t part;        // partition of the running search
-  int32_t bits;        // its filter size (log2)
-  int32_t pred[6];     // nodes likely to be visited next (-1: none)
-  int32_t pad[6];
+constexpr int kPkSlots = 12;
+constexpr int kReqRing = 16;
+static_assert(kPkSlots % kHelpers == 0 && kReqRing >= kPkSlots, "request -> helper / slot mapping");
+struct ScoreBox {     // LDS mailbox; head written by the search wave, packet slot s by helper s % kHelpers
+  int32_t gen;        // < 0: the kernel is ending; 0: no search is running; > 0: generation of the running search
+  int32_t req_head;   // requests the running search has issued
+  int32_t part;       // its partition
+  int32_t bits;       // its filter size (log2)
+  int32_t qid_lo, qid_hi;  // the query's own id (never scored, beamSearch.h:128)
+  int32_t last_gen;   // the last generation used (generations never repeat within a launch)
+  int32_t pad0;
+  int32_t req[kReqRing];                // request i: the node, at i % kReqRing
+  unsigned long long tag[kPkSlots];     // (generation << 32 | node) of a complete packet; 0 while a helper rewrites the slot
+  unsigned long long mask[kPkSlots];    // lanes of the row whose distance the packet holds
+  int32_t flags[kPkSlots];              // bit 0: two valid lanes of the row share a filter slot
+  int32_t row[kPkSlots][64];            // adjacency row (-1: unused slot)
+  uint32_t loc[kPkSlots][64];           // filter slot of each neighbour
+  float dist[kPkSlots][64];
 };
+static_assert(sizeof(ScoreBox) <= kScoreBoxBytes, "ScoreBox outgrew its LDS reservation");
+// The mailbox is polled, so its accesses are volatile -- through a pointer that carries the LDS address space: hipcc's
+// address-space inference leaves volatile accesses through a generic pointer alone, and they become FLAT loads / stores
+// (sc0 sc1) that wait for every outstanding global load of the wave.
+typedef __attribute__((address_space(3))) volatile ScoreBox LdsBox;
+__device__ __forceinline__ LdsBox *lds_box(ScoreBox *b) { return (LdsBox *)b; }
 
-__device__ __forceinline__ void prefetch_helper(const IndexView &ix, int32_t *gtable, const uint32_t *gseen, int degree_limit,
-                                                PrefetchBox *box) {
+template <int METRIC, bool LEAN = false>
+__device__ __forceinline__ float wave_distances_own(const IndexView &ix, int a, bool take, const float *qv, int64_t row_off);
+
+template <int METRIC>
+__device__ __forceinline__ void score_helper(const IndexView &ix, int32_t *gtable, const uint32_t *gseen, int degree_limit,
+                                             ScoreBox *box, const float *qv, int hidx) {
   const int lane = lane_id();
-  constexpr int K = 8;
-  int rid = -1, rst = 0;  // lane e < K: node of ring slot e, its stage (0 free, 1 row requested, 2 probes issued, 3 done)
-  int rrow[K];
-  uint32_t rE[K];
-#pragma unroll
-  for (int e = 0; e < K; e++) {
-    rrow[e] = -1;
-    rE[e] = 0;
-  }
-  int my_gen = 0, my_seq = -1, head = 0;
-  int64_t row_base = 0, row_off = 0;
+  LdsBox *vb = lds_box(box);
+  int my_gen = 0, next = hidx, bits = 10;
+  int64_t row_base = 0, row_off = 0, qid = -1;
   uint32_t tmask = 0;
-  const int lpr = (ix.stride * 4 + 127) >> 7;  // 128-B lines per vector row
   for (;;) {
-    const int gen = *(volatile int32_t *)&box->gen;
+    const int gen = vb->gen;
     if (gen < 0) return;
     if (gen == 0) {
       my_gen = 0;
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(8);
       continue;
     }
-    if (gen != my_gen) {  // a new search: forget the ring
+    if (gen != my_gen) {  // a new search (its query is staged and its head fields are written before the generation)
       my_gen = gen;
-      my_seq = -1;
-      rid = -1;
-      rst = 0;
-      head = 0;
-      const PartDesc pd = ix.parts[*(volatile int32_t *)&box->part];
+      next = hidx;
+      const PartDesc pd = ix.parts[vb->part];
       row_base = pd.row_base;
       row_off = pd.start;
-      tmask = (1u << *(volatile int32_t *)&box->bits) - 1u;
+      bits = vb->bits;
+      tmask = (1u << bits) - 1u;
+      qid = ((int64_t)vb->qid_hi << 32) | (uint32_t)vb->qid_lo;
     }
-    bool issued = false;
-    // ---- what was requested in the previous round has arrived (the registers are read below): next stage
-#pragma unroll
-    for (int e = 0; e < K; e++) {
-      const int st = rdlane(rst, e);
-      if (st == 1) {  // row -> filter slots and seen-set words of its neighbours
-        const int a = rrow[e];
-        const bool valid = (a >= 0) && (lane < degree_limit);
-        uint32_t w = ~0u;
-        if (valid) {
-          const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
-          (void)*reinterpret_cast<const volatile int32_t *>(gtable + loc);
-          w = gseen[a >> 5];
-        }
-        rE[e] = w;
-        if (lane == e) rst = 2;
-        issued = true;
-      } else if (st == 2) {  // seen-set words -> vector lines of the neighbours that are not scored yet
-        const int a = rrow[e];
-        const bool want = (a >= 0) && (lane < degree_limit) && !((rE[e] >> (a & 31)) & 1u);
-        if (want) {
-          const float *row = ix.points + (row_off + a) * (int64_t)ix.stride;
-          for (int l = 0; l < lpr; l++) (void)*reinterpret_cast<const volatile int *>(row + l * 32);
-        }
-        if (lane == e) rst = 3;
-        issued = true;
-      }
+    const int head = vb->req_head;
+    while (head - next > kReqRing - 4) next += kHelpers;  // far behind: those ring entries are gone, nobody waits for them
+    if (next >= head) {
+      __builtin_amdgcn_s_sleep(1);
+      continue;
     }
-    // ---- new predictions: request their rows
-    const int seq = *(volatile int32_t *)&box->seq;
-    if (seq != my_seq) {
-      my_seq = seq;
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int pnode = *(volatile int32_t *)&box->pred[j];
-        if (pnode < 0 || ballot64(lane < K && rid == pnode)) continue;
-        const int slot = head & (K - 1);
-        head++;
-        if (lane == slot) {
-          rid = pnode;
-          rst = 1;
-        }
-        int a = -1;
-        if (lane < ix.rs) a = ix.graph[(row_base + pnode) * (int64_t)ix.rs + lane];
-#pragma unroll
-        for (int e = 0; e < K; e++)
-          if (slot == e) rrow[e] = a;
-        issued = true;
-      }
+    const int pnode = vb->req[next & (kReqRing - 1)];
+    const int sl = next % kPkSlots;
+    next += kHelpers;
+    if (lane == 0) vb->tag[sl] = 0ull;  // readers of the old packet notice (this wave's LDS operations execute in order)
+    int a = -1;
+    if (lane < ix.rs) a = ix.graph[(row_base + pnode) * (int64_t)ix.rs + lane];
+    const bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+    const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
+    uint32_t w = ~0u;
+    int touch = 0;
+    if (valid) {
+      touch = gtable[loc];  // the search wave's filter probe will hit the L2
+      w = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!issued) __builtin_amdgcn_s_sleep(8);
+    // do two valid lanes of the row share a filter slot?  (exact, by `bits` ballots: this wave is not on the critical path)
+    u64 eq = ballot64(valid);
+    for (int b = 0; b < bits; b++) {
+      const bool bit = (loc >> b) & 1u;
+      const u64 bm = ballot64(valid && bit);
+      eq &= bit ? bm : ~bm;
+    }
+    const int clash = ballot64(valid && (eq & ~((u64)1 << lane)) != 0) != 0 ? 1 : 0;
+    const bool want = valid && !((w >> (a & 31)) & 1u);
+    const float dd = wave_distances_own<METRIC>(ix, a, want, qv, row_off);
+    vb->row[sl][lane] = a;
+    vb->loc[sl][lane] = loc;
+    vb->dist[sl][lane] = dd;
+    const u64 wm = ballot64(want);
+    asm volatile("" ::"v"(touch));  // (the touch is a real load)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {
+      vb->mask[sl] = wm;
+      vb->flags[sl] = clash;
+      vb->tag[sl] = ((u64)(uint32_t)gen << 32) | (uint32_t)pnode;
+    }
   }
 }
 
@@ -961,7 +978,8 @@ __device__ __forceinline__ int pair_even_value(int v) {
   return (lane_id() & 1) ? sw : v;
 }
 
-template <int METRIC>
+// LEAN: the routines that keep half a row per lane pair in flight (same arithmetic, same order; for callers short of registers).
+template <int METRIC, bool LEAN>
 __device__ __forceinline__ float wave_distances_own(const IndexView &ix, int a, bool take, const float *qv, int64_t row_off) {
   const int lane = lane_id();
   const int h = lane & 1;
@@ -981,7 +999,10 @@ __device__ __forceinline__ float wave_distances_own(const IndexView &ix, int a, 
 #if WANN_DT != 0
     dd = byte_pair<METRIC>(prow, qv, ix.stride, h);
 #else
-    if (METRIC == 1) {
+    if (LEAN) {
+      if (METRIC == 1) dd = mips_pair(prow, qv, ix.d, h);
+      else dd = l2_pair<8>(prow, qv, (ix.d + 7) >> 3, h, true);
+    } else if (METRIC == 1) {
       const int np = (((ix.d + 3) >> 2) + 1) >> 1;
       switch (np) {  // wave-uniform
         case 12: dd = mips_pair_ct<12>(prow, qv, ix.d, h); break;
@@ -1012,27 +1033,52 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
                                                      int64_t qid, int64_t limit, int degree_limit, int32_t *mini,
                                                      uint32_t mini_mask, int &m_out, long long &nvis_out,
                                                      long long &ncmp_out, unsigned long long *prof = nullptr,
-                                                     PrefetchBox *box = nullptr, int part_index = 0,
-                                                     const int32_t *abort_flag = nullptr) {
+                                                     ScoreBox *box = nullptr, int part_index = 0,
+                                                     const int32_t *abort_flag = nullptr, Counters *ctr = nullptr) {
   // abort_flag: a look-ahead search (k_search) that its chain has withdrawn (*abort_flag == 2) stops at the next check
+  //
+  // A search wave runs alone on its SIMD, so every dependent instruction costs its full latency and every trip between
+  // the vector and the scalar side (ballot -> branch -> readlane ...) a few dozen cycles.  The hop below therefore keeps
+  // its working set in registers: a 64-entry WINDOW of the LDS beam around the first unvisited entry with its unvisited
+  // mask (the next node is a bit scan, not a beam read), the delta list's first unvisited and last keys and the cutoff as
+  // scalars, the beam's last 64 entries as a TAIL cache for the truncation, and packet requests in beam order (the k-th
+  // outstanding request belongs to the k-th unvisited entry: finding a packet needs no lookup).
   prof = WANN_PROF_PTR(prof);
+  // Every wave-uniform argument into scalar registers, explicitly: ONE value the compiler can not prove uniform (a pointer
+  // selected by a loaded flag, say) in ONE exit test makes the whole hop loop "divergent" -- and then every loop-carried
+  // scalar (list sizes, window mask, cutoff ...) lives in vector registers under exec masks.
+  const bool check_abort = uni((int)(abort_flag != nullptr)) != 0;
+  tag = (uint32_t)uni((int)tag);
+  B = uni(B);
+  bits = uni(bits);
+  qid = uni64(qid);
+  limit = uni64(limit);
+  degree_limit = uni(degree_limit);
+  mini_mask = (uint32_t)uni((int)mini_mask);
+  part_index = uni(part_index);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
-  const int64_t row_off = part.start;
+  const int64_t row_off = uni(part.start);
+  const int64_t row_base = uni64(part.row_base);
+  const int part_n = uni(part.n);
   u64 *const mb = L.lbeam;
-  if (box && lane == 0) {  // a new search for the prefetch helper wave
-    volatile int32_t *vb = reinterpret_cast<volatile int32_t *>(box);
-    vb[2] = part_index;
-    vb[3] = bits;
-    for (int j = 0; j < 6; j++) vb[4 + j] = -1;
-    vb[1] = 0;
-    const int g = vb[10] + 1;  // pad[0]: the last generation used (generations never repeat within a launch)
-    vb[10] = g;
-    vb[0] = g;
+  LdsBox *const vb = lds_box(box);
+  int my_gen = 0, st_pk = 0, st_own = 0, st_nx = 0;
+  if (box) {  // a new search for the helper waves (the query is staged already)
+    if (lane == 0) {
+      vb->part = part_index;
+      vb->bits = bits;
+      vb->qid_lo = (int32_t)(uint32_t)qid;
+      vb->qid_hi = (int32_t)(qid >> 32);
+      vb->req_head = 0;
+      my_gen = vb->last_gen + 1;
+      vb->last_gen = my_gen;
+    }
+    my_gen = uni(my_gen);
   }
   {  // exact seen set of this search: empty
     int4 *sv = reinterpret_cast<int4 *>(gseen);
-    const int n16 = (part.n + 127) >> 7;
+    const int n16 = (part_n + 127) >> 7;
     for (int i = lane; i < n16; i += 64) sv[i] = make_int4(0, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in L2 before the first probe (probes and updates are L2 atomics)
   }
@@ -1041,70 +1087,101 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   WAVE_SYNC();
   float d0 = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, 1, row_off);
   d0 = __shfl(d0, 0);
+  const u64 key0 = (u64)fkey(d0) << 32;
   if (lane == 0) {
-    mb[0] = (u64)fkey(d0) << 32;
+    mb[0] = key0;
     __hip_atomic_fetch_or(gseen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (box) vb->gen = my_gen;  // (after the seen set's clear: the helpers read it)
   }
   WAVE_SYNC();
-  int M = 1, D = 0;            // entries in the LDS beam / in the delta list
-  u64 dk = ~0ull;              // delta list: lane i < D holds its i-th smallest key; ~0 elsewhere
-  int pm = 0;                  // first unvisited entry of the LDS beam (M: none)
-  u64 pmk = (u64)fkey(d0) << 32;  // its key (~0: none)
-  u64 mlk = pmk;               // key of the last entry of the LDS beam, mb[M - 1] (0: empty)
-  int nvis = 0, ncmp = 1;
+  int M = 1, D = 0;               // entries in the LDS beam / in the delta list
+  u64 dk = ~0ull;                 // delta list: lane i < D holds its i-th smallest key; ~0 elsewhere
+  u64 dhead = ~0ull, dlast = 0;   // its smallest unvisited key (~0: none) and its last key (0: empty), wave-uniform
+  u64 mlk = key0;                 // key of the last entry of the LDS beam, mb[M - 1] (0: empty)
+  float cutoff = 2147483648.0f;   // (float)INT_MAX while the beam is not full, else its last distance (beamSearch.h:135-137)
+  // window: wv = mb[wbase + lane]; bit i of wum: entry wbase + i is unvisited (and exists); pmk = the first such key (~0: none)
+  int wbase = 0;
+  u64 wv = lane == 0 ? key0 : 1ull, wum = 1ull, pmk = key0;
+  int tb = 0;                     // tail cache: tv = mb[tb + lane]
+  u64 tv = lane == 0 ? key0 : 0ull;
+  // packet requests: entries of the LDS beam up to position req_pos have been requested, in beam order; rq_next is the
+  // request of the first unvisited one among them (requests rq_next .. nreq - 1 are outstanding)
+  int nreq = 0, rq_next = 0, req_pos = -1;
+  // the node this wave expects to visit next, with its packet and its filter / seen-set probes (issued during this hop's
+  // insertion, consumed by the next hop if the expectation holds)
+  int nx_node = -1, nx_a = -1, nx_old = -1, nx_flags = 0;
+  uint32_t nx_loc = 0, nx_sw = 0;
+  float nx_dist = 0.f;
+  u64 nx_mask = 0;
+  int nvis = 0, ncmp_v = 0;  // (dist_cmps: counted per lane, summed at the end)
   const int lim = limit > 0x7fffffff ? 0x7fffffff : (int)limit;
-  auto load_last = [&]() {
-    u64 v = 0;
-    if (M > 0) v = mb[M - 1];  // uniform address: an LDS broadcast
-    mlk = rdlane64(v, 0);
-  };
-  // pm = first unvisited entry at or after s; with a helper wave the next unvisited entries of the same chunk are
-  // published as the nodes to prefetch
-  auto rescan = [&](int s, bool publish) {
-    pm = M;
-    pmk = ~0ull;
-    while (s < M) {
+
+  auto load_window = [&](int s) {  // the first chunk at or after s that holds an unvisited entry
+    for (;;) {
       const int x = s + lane;
-      const u64 v = x < M ? mb[x] : 1ull;
-      u64 um = ballot64(!(v & 1ull));
-      if (um) {
-        const int i = ctz64(um);
-        pm = s + i;
-        pmk = rdlane64(v, i);
-        if (publish && box) {
-          int pr[3];
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            pr[j] = -1;
-            if (um) {
-              pr[j] = (int)((uint32_t)rdlane((int)(uint32_t)v, ctz64(um)) >> 1);
-              um &= um - 1;
-            }
-          }
-          if (lane == 0) {
-            volatile int32_t *vb = reinterpret_cast<volatile int32_t *>(box);
-            vb[4] = pr[0];
-            vb[5] = pr[1];
-            vb[6] = pr[2];
-            vb[1] = vb[1] + 1;
-          }
-        }
-        break;
-      }
+      wv = x < M ? mb[x] : 1ull;
+      wum = ballot64(!(wv & 1ull));
+      wbase = s;
+      if (wum || s + 64 >= M) break;
       s += 64;
     }
+    pmk = wum ? rdlane64(wv, ctz64(wum)) : ~0ull;
+  };
+  auto load_tail = [&]() {
+    tb = M > 64 ? M - 64 : 0;
+    const int x = tb + lane;
+    tv = x < M ? mb[x] : 0ull;
+    mlk = M ? rdlane64(tv, M - 1 - tb) : 0ull;
+  };
+  auto set_cutoff = [&]() {
+    cutoff = 2147483648.0f;
+    if (M + D >= B) cutoff = funkey((uint32_t)(((mlk | 1ull) > (dlast | 1ull) ? mlk : dlast) >> 32));
+  };
+  auto forget_requests = [&]() {  // nothing at or after the first unvisited entry counts as requested
+    rq_next = nreq;
+    req_pos = wbase + (wum ? ctz64(wum) : 64) - 1;
+  };
+  // everything above from (mb, M, dk, D) -- after a merge of the LDS beam
+  auto resync = [&](int s) {
+    load_tail();
+    load_window(s);
+    const u64 du = ballot64(lane < D && !(dk & 1ull));
+    dhead = du ? rdlane64(dk, ctz64(du)) : ~0ull;
+    dlast = D ? rdlane64(dk, D - 1) : 0ull;
+    set_cutoff();
+    forget_requests();
+    nx_node = -1;
+  };
+  // the complete packet of `node` in slot sl, if its helper has finished it: every field is read between two reads of the
+  // slot's tag (the helper zeroes the tag before it rewrites a slot; LDS operations of a wave execute in order)
+  auto read_packet = [&](int sl, int node, int &pa, uint32_t &ploc, float &pdist, u64 &pmask, int &pflags) -> bool {
+    const u64 want = ((u64)(uint32_t)my_gen << 32) | (uint32_t)node;
+    const u64 t1 = vb->tag[sl];
+    const int ra = vb->row[sl][lane];
+    const uint32_t rl = vb->loc[sl][lane];
+    const float rd = vb->dist[sl][lane];
+    const u64 rm = vb->mask[sl];
+    const int rf = vb->flags[sl];
+    const u64 t2 = vb->tag[sl];
+    if (!uni((int)(t1 == want && t2 == want))) return false;
+    pa = ra;
+    ploc = rl;
+    pdist = rd;
+    pmask = rm;         // (the same value in every lane)
+    pflags = rf | 2;    // bit 1: the row's slot-sharing test is known (bit 0)
+    return true;
   };
   auto flush = [&]() {  // merge the delta list into the LDS beam
     if (D == 0) return;
+    const int pm = wum ? wbase + ctz64(wum) : M;
     int p0;
     M = wave_merge<u64 *, false, true>(mb, M, B, lane < D, dk, L.cand_key, &p0);
     D = 0;
     dk = ~0ull;
-    load_last();
-    rescan(pm < p0 ? pm : p0, false);
+    resync(pm < p0 ? pm : p0);
   };
 
-  unsigned long long tp = 0, acc[6] = {0, 0, 0, 0, 0, 0}, pacc[3] = {0, 0, 0}, tw0 = 0;
+  unsigned long long tp = 0, acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define WANN_PHASE(i)                                       \
   do {                                                      \
     if (prof) {                                             \
@@ -1115,83 +1192,138 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   } while (0)
   if (prof) tp = __builtin_readcyclecounter();
   for (;;) {
+    // The loop-carried scalars, declared uniform once per hop.  For the compiler a value is divergent as soon as it is merged
+    // at the join of ANY lane-dependent branch (`if (valid) store` next to `flag = ...` is enough), and one such value in
+    // one exit test turns the whole loop into an exec-masked one with every scalar in vector registers.  A readfirstlane of
+    // a value the compiler already knows to be uniform folds away.
+    M = uni(M);
+    D = uni(D);
+    wbase = uni(wbase);
+    tb = uni(tb);
+    nreq = uni(nreq);
+    rq_next = uni(rq_next);
+    req_pos = uni(req_pos);
+    nx_node = uni(nx_node);
+    nvis = uni(nvis);
+    wum = (u64)uni64((long long)wum);
+    pmk = (u64)uni64((long long)pmk);
+    dhead = (u64)uni64((long long)dhead);
+    dlast = (u64)uni64((long long)dlast);
+    mlk = (u64)uni64((long long)mlk);
+    cutoff = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cutoff)));
     // ---- visit the closest unvisited entry of the beam (beamSearch.h:108-117): the closer of the first unvisited
     //      entry of the LDS beam and the first unvisited entry of the delta list
-    const u64 du = ballot64(lane < D && !(dk & 1ull));
-    if ((pmk == ~0ull && du == 0) || nvis >= lim) break;
-    if (abort_flag && (nvis & 31) == 0) {
+    if ((pmk == ~0ull && dhead == ~0ull) || nvis >= lim) break;
+    if (check_abort && (nvis & 31) == 0) {
       int ab = 0;
       if (lane == 0) ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (uni(ab) == 2) break;
     }
-    int cur = 0;
-    bool from_delta = false;
-    if (du) {
-      const int dl = ctz64(du);
-      const u64 dkey = rdlane64(dk, dl);
-      if ((dkey | 1ull) < (pmk | 1ull)) {
-        from_delta = true;
-        cur = (int)((uint32_t)dkey >> 1);
-        if (lane == dl) dk |= 1ull;
-      }
-    }
-    if (!from_delta) {
+    const bool from_delta = (dhead | 1ull) < (pmk | 1ull);
+    int cur;
+    bool consumed = false;  // the visited entry had a packet requested
+    if (from_delta) {
+      cur = (int)((uint32_t)dhead >> 1);
+      if (dk == dhead) dk |= 1ull;  // (keys are unique)
+      const u64 du = ballot64(lane < D && !(dk & 1ull));
+      dhead = du ? rdlane64(dk, ctz64(du)) : ~0ull;
+    } else {
+      const int i = ctz64(wum);
       cur = (int)((uint32_t)pmk >> 1);
-      if (lane == 0) mb[pm] = pmk | 1ull;
+      if (lane == 0) mb[wbase + i] = pmk | 1ull;
+      wum &= wum - 1;
+      consumed = wbase + i <= req_pos;
     }
     nvis++;
-    // ---- adjacency row, coalesced (graph.h:198); -1 = unused slot
-    int a = -1;
-    if (prof) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      tw0 = __builtin_readcyclecounter();
-    }
-    if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
-    if (prof) {  // pure load latency of the row
+    WANN_PHASE(0);  // select
+    if (prof) {  // (profile builds: how long the probes issued during the previous hop are still in flight)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pacc[0] += __builtin_readcyclecounter() - tw0;
+      WANN_PHASE(9);
     }
-    if (!from_delta) {  // (LDS only: overlaps the row's flight)
-      WAVE_SYNC();
-      rescan(pm + 1, true);
+
+    // ---- adjacency row (graph.h:198; -1 = unused slot), the neighbours' filter slots and the two probes: prepared during
+    //      the previous hop if this is the node it expected; else from a helper's packet; else from memory
+    int a = -1, old = -1, flags = 0;
+    uint32_t loc = 0, sw = 0;
+    float pk_dist = 0.f;
+    u64 pk_mask = 0;
+    bool valid;
+    if (cur == nx_node && !from_delta) {
+      st_nx += (lane == 0) ? 1 : 0;
+      a = nx_a;
+      loc = nx_loc;
+      old = nx_old;
+      sw = nx_sw;
+      pk_dist = nx_dist;
+      pk_mask = nx_mask;
+      flags = nx_flags;
+      valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+    } else {
+      if (!(box && consumed && read_packet(rq_next % kPkSlots, cur, a, loc, pk_dist, pk_mask, flags))) {
+        if (lane < ix.rs) a = ix.graph[(row_base + cur) * (int64_t)ix.rs + lane];
+        loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
+      }
+      valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+      if (valid) {
+        old = gtable[loc];
+        sw = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-    const bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
-    if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WANN_PHASE(0);  // row fetch
+    if (consumed) rq_next++;
+    nx_node = -1;
+    st_pk += (lane == 0 && (flags & 2)) ? 1 : 0;  // (lane-dependent on purpose: a statistic must not cost a scalar register)
+    WANN_PHASE(1);  // row, filter slots, probes
+
+    // ---- the window follows the first unvisited entry; packets are requested for the next four unvisited entries
+    if (!from_delta) {
+      if (popc64(wum) < 4 && wbase + 64 < M) load_window(wum ? wbase + ctz64(wum) : wbase + 64);
+      else pmk = wum ? rdlane64(wv, ctz64(wum)) : ~0ull;
+    }
+    if (box) {
+#pragma unroll
+      for (int r = 0; r < 2; r++) {  // (one per hop keeps the distance; two catch up after a restart)
+        u64 cand = wum;
+        const int rel = req_pos - wbase;  // window bits <= rel have been requested
+        if (rel >= 63) cand = 0;
+        else if (rel >= 0) cand &= ~(((u64)2 << rel) - 1);
+        if (!cand) break;
+        const int j = ctz64(cand);
+        if (popc64(wum & (((u64)1 << j) - 1)) >= 4) break;
+        const int node = (int)((uint32_t)rdlane((int)(uint32_t)wv, j) >> 1);
+        if (lane == 0) {
+          vb->req[nreq & (kReqRing - 1)] = node;
+          vb->req_head = nreq + 1;
+        }
+        nreq++;
+        req_pos = wbase + j;
+      }
+    }
+    WANN_PHASE(2);  // next unvisited entry + packet requests
 
     // ---- lossy seen-filter (sequential semantics, beamSearch.h:68-73,126-131) + exact seen set
-    const uint32_t loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
     const int tagged = (int)(tag | (uint32_t)a);
-    int old = -1;
-    uint32_t sw = 0;
-    if (prof) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      tw0 = __builtin_readcyclecounter();
+    bool clash;
+    if (flags & 2) clash = (flags & 1) != 0;  // (the helper's exact test)
+    else {
+      // exact test "two valid lanes of the row share a filter slot": every lane tags its slot of a small LDS hash with
+      // its lane number; a lane that lost its slot compares filter slots with the winner, and the few lanes whose
+      // loss was a collision of the small hash only are compared with all lanes
+      const uint32_t mh = loc & mini_mask;
+      if (valid) mini[mh] = lane;
+      WAVE_SYNC();
+      const int mw = valid ? mini[mh] : lane;
+      WAVE_SYNC();
+      const uint32_t loc_w = (uint32_t)__shfl((int)loc, mw);
+      const bool lost = valid && (mw != lane);
+      clash = ballot64(lost && loc_w == loc) != 0;
+      for (u64 um = ballot64(lost && loc_w != loc); um && !clash; um &= um - 1) {
+        const int u = ctz64(um);
+        const uint32_t lu = (uint32_t)rdlane((int)loc, u);
+        clash = ballot64(valid && loc == lu && lane != u) != 0;
+      }
     }
-    if (valid) {
-      old = gtable[loc];
-      sw = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (prof) {  // pure load latency of the two probes
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pacc[1] += __builtin_readcyclecounter() - tw0;
-    }
-    // exact test "two valid lanes of the row share a filter slot": every lane tags its slot of a small LDS hash with
-    // its lane number; a lane that lost its slot compares filter slots with the winner, and the few lanes whose
-    // loss was a collision of the small hash only are compared with all lanes
-    const uint32_t mh = loc & mini_mask;
-    if (valid) mini[mh] = lane;
-    WAVE_SYNC();
-    const int mw = valid ? mini[mh] : lane;
-    WAVE_SYNC();
-    const uint32_t loc_w = (uint32_t)__shfl((int)loc, mw);
-    const bool lost = valid && (mw != lane);
-    bool clash = ballot64(lost && loc_w == loc) != 0;
-    for (u64 um = ballot64(lost && loc_w != loc); um && !clash; um &= um - 1) {
-      const int u = ctz64(um);
-      const uint32_t lu = (uint32_t)rdlane((int)loc, u);
-      clash = ballot64(valid && loc == lu && lane != u) != 0;
-    }
+    clash = uni((int)clash) != 0;
+    WANN_PHASE(3);  // slot-sharing test
     bool seen, twice = false;
     if (!clash) {
       seen = valid && (old == tagged);
@@ -1220,84 +1352,114 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       }
       twice = ballot64(twice) != 0;
     }
+    twice = uni((int)twice) != 0;  // (a uniform flag merged at the join of a lane-dependent branch counts as divergent)
     const bool kept = valid && !seen;  // what the reference scores
-    ncmp += popc64(ballot64(kept));
+    ncmp_v += kept ? 1 : 0;
     const bool fresh = kept && !((sw >> (a & 31)) & 1u);
     const bool take = twice ? kept : fresh;  // what is computed
     if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    WANN_PHASE(1);  // seen-filter
+    WANN_PHASE(4);  // seen-filter
+
+    // ---- the next hop's node, as far as one can tell now (a candidate of this hop may still come first): its packet and
+    //      its probes are fetched while this hop's candidates are inserted.  The probes are issued after this hop's filter
+    //      stores and seen-set updates (same wave, program order), so they see them.
+    if (box && wum && !((dhead | 1ull) < (pmk | 1ull)) && wbase + ctz64(wum) <= req_pos) {
+      const int nn = (int)((uint32_t)pmk >> 1);
+      if (read_packet(rq_next % kPkSlots, nn, nx_a, nx_loc, nx_dist, nx_mask, nx_flags)) {
+        nx_node = nn;
+        // (no lane-dependent branch around the loads: an unused slot's filter slot lies inside the table like any other,
+        // and its seen-set word is read at node 0)
+        nx_old = gtable[nx_loc & tmask];
+        nx_sw = __hip_atomic_load(gseen + ((nx_a < 0 ? 0 : nx_a) >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    WANN_PHASE(5);  // next hop's packet and probes
 
     if (twice) flush();  // the exact multiset union below works on the whole beam
-    // ---- score (beamSearch.h:135-145)
-    float cutoff = 2147483648.0f;  // (float)INT_MAX
-    if (M + D >= B) {
-      const u64 dlast = D ? rdlane64(dk, D - 1) : 0ull;
-      cutoff = funkey((uint32_t)(((mlk | 1ull) > (dlast | 1ull) ? mlk : dlast) >> 32));
+    // ---- score (beamSearch.h:135-145).  Distances: from the packet where it holds them; what it lacks (no packet, or a
+    //      neighbour the helper took for scored already) is computed here
+    float dist = pk_dist;
+    const bool need = take && !((pk_mask >> lane) & 1ull);
+    if (ballot64(need)) {
+      st_own += (lane == 0) ? 1 : 0;
+      // (the delta list waits in the merge scratch meanwhile: the scoring routine keeps a whole row per lane pair in
+      // flight and needs every register)
+      L.cand_key[lane] = dk;
+      const float own = wave_distances_own<METRIC, true>(ix, a, need, L.qv, row_off);
+      dk = L.cand_key[lane];
+      if (need) dist = own;
     }
-    if (prof) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      tw0 = __builtin_readcyclecounter();
-    }
-    // (the delta list waits in the merge scratch meanwhile: the scoring routine keeps two whole rows per lane pair in
-    // flight and needs every register)
-    L.cand_key[lane] = dk;
-    const float dist = wave_distances_own<METRIC>(ix, a, take, L.qv, row_off);
-    dk = L.cand_key[lane];
-    if (prof) pacc[2] += __builtin_readcyclecounter() - tw0;  // the scoring routine alone
     const bool pass = take && (dist < cutoff);
     const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
-    WANN_PHASE(2);  // vector fetch + distances
+    const u64 pmask = ballot64(pass);
+    WANN_PHASE(6);  // distances
 
     // ---- union + truncate (beamSearch.h:148-157)
-    const u64 pmask = ballot64(pass);
     if (twice) {
       int p0;
+      const int pm = wum ? wbase + ctz64(wum) : M;
       M = wave_merge(mb, M, B, pass, key, L.cand_key, &p0);
-      load_last();
-      rescan(pm < p0 ? pm : p0, false);
+      resync(pm < p0 ? pm : p0);
     } else if (pmask) {
-      const int c = popc64(pmask);
-      if (D + c > 64) flush();
-      for (u64 mm = pmask; mm; mm &= mm - 1) {  // into the delta list, one lane shift each
+      if (D + popc64(pmask) > 64) flush();
+      for (u64 mm = pmask; mm; mm &= mm - 1) {  // into the delta list: vector operations only after the broadcast
         const u64 k = rdlane64(key, ctz64(mm));
-        const int pos = popc64(ballot64(lane < D && (dk | 1ull) < (k | 1ull)));
+        const bool lt = (dk | 1ull) < (k | 1ull);  // (lanes >= D hold ~0: never)
+        const int f = lt ? 1 : 0;
+        const int fprev = __builtin_amdgcn_update_dpp(1, f, 0x138, 0xf, 0xf, false);  // lane - 1's; lane 0: 1
         const u64 up = wave_shr1(dk);
-        dk = lane < pos ? dk : (lane == pos ? k : up);
+        dk = lt ? dk : (fprev ? k : up);
         D++;
+        if ((k | 1ull) < (dhead | 1ull)) dhead = k;
+        if ((k | 1ull) > (dlast | 1ull)) dlast = k;
       }
-      const int excess = M + D - B;
-      if (excess > 0) {
-        // truncate to B: the `excess` largest entries of (LDS beam, delta list) leave.  Both are sorted; delta entry
-        // i-from-the-end is among them iff fewer than excess - i beam entries exceed it, i.e. iff the beam entry
-        // excess - i - 1 from the end (if there is one) is smaller.
-        const int ai = D - 1 - lane;
-        const u64 av = __shfl(dk, ai >= 0 ? ai : 0);  // delta, from the end
-        const int bi = M - excess + lane;
-        const u64 bv = (lane < excess && bi >= 0) ? mb[bi] : 0ull;
-        const bool leaves = lane < excess && ai >= 0 && (bi < 0 || (bv | 1ull) < (av | 1ull));
-        const int t = popc64(ballot64(leaves));
-        D -= t;
-        if (lane >= D) dk = ~0ull;
-        M -= excess - t;
-        load_last();
-        if (pm >= M) {
-          pm = M;
-          pmk = ~0ull;
+      WANN_PHASE(7);  // into the delta list
+      // truncate to B: the largest entry of (LDS beam, delta list) leaves, `excess` times; both are sorted
+      for (int excess = M + D - B; excess > 0; excess--) {
+        if (D > 0 && (M == 0 || (dlast | 1ull) > (mlk | 1ull))) {
+          if (lane == D - 1) dk = ~0ull;
+          D--;
+          if (dlast == dhead) dhead = ~0ull;  // (it was the only unvisited entry)
+          dlast = D ? rdlane64(dk, D - 1) : 0ull;
+        } else {
+          M--;
+          if (M == 0) mlk = 0;
+          else if (M - 1 >= tb) mlk = rdlane64(tv, M - 1 - tb);
+          else load_tail();
         }
       }
+      if (M < wbase + 64) {  // the window lost entries
+        const int keep = M - wbase;
+        wum = keep <= 0 ? 0ull : (wum & ((((u64)1 << (keep - 1)) << 1) - 1));
+        if (!wum) pmk = ~0ull;
+        if (M - 1 < req_pos) {
+          forget_requests();
+          nx_node = -1;
+        }
+      }
+      set_cutoff();
     }
-    WANN_PHASE(3);  // insertion
+    WANN_PHASE(8);  // truncation
   }
 #undef WANN_PHASE
-  if (box && lane == 0) *reinterpret_cast<volatile int32_t *>(box) = 0;  // (the next search picks the next generation)
-  flush();
-  if (prof && lane == 0) {
-    for (int i = 0; i < 5; i++) atomicAdd(&prof[i], acc[i]);
-    for (int i = 0; i < 3; i++) atomicAdd(&prof[5 + i], pacc[i]);
+  if (box && lane == 0) vb->gen = 0;  // (the next search picks the next generation)
+  if (D) {
+    int p0;
+    M = wave_merge<u64 *, false, true>(mb, M, B, lane < D, dk, L.cand_key, &p0);
+  }
+  for (int o = 32; o; o >>= 1) ncmp_v += __shfl_xor(ncmp_v, o);
+  if (prof && lane == 0)
+    for (int i = 0; i < 10; i++) atomicAdd(&prof[i], acc[i]);
+  if (ctr && lane == 0) {
+    atomicAdd(&ctr->big_searches, 1ull);
+    atomicAdd(&ctr->big_hops, (unsigned long long)nvis);
+    atomicAdd(&ctr->packet_hops, (unsigned long long)st_pk);
+    atomicAdd(&ctr->own_scorings, (unsigned long long)st_own);
+    atomicAdd(&ctr->prefetched_hops, (unsigned long long)st_nx);
   }
   m_out = M;
   nvis_out = nvis;
-  ncmp_out = ncmp;
+  ncmp_out = 1 + ncmp_v;
 }
 
 // --------------------------------------------------------------------------------------------

@@ -152,6 +152,13 @@ class Index {
     d["gemm_rescued"] = c.gemm_rescued;
     d["deep_handoffs"] = c.deep_handoffs;
     d["lookaheads_used"] = c.lookaheads_used;
+    d["big_searches"] = c.big_searches;
+    d["big_hops"] = c.big_hops;
+    d["packet_hops"] = c.packet_hops;
+    d["own_scorings"] = c.own_scorings;
+    d["prefetched_hops"] = c.prefetched_hops;
+    d["poll_timeouts"] = c.poll_timeouts;
+    d["lookaheads_issued"] = c.lookaheads_issued;
     d["recovered_continuations"] = c.recovered_continuations;
     d["device_ms"] = c.device_ms;
     d["search_kernel_ms"] = c.search_kernel_ms;

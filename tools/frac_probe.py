@@ -39,7 +39,7 @@ for p in [int(x) for x in args.fractions.split(",")]:
             best = c if best is None or c["device_ms"] < best["device_ms"] else best
         rec = B.recall_of(torch, gt, gcnt, ids_t)
         print(f"2^{p} beam {beam} x{mult}: recall {rec:.4f} device {best['device_ms']:.2f} ms kernel {best['search_kernel_ms']:.2f} ms rounds {best['rounds']} "
-              f"searches {best['beam_searches']} hops {best['hops']} spec_searches {best['spec_searches']} spec_hops {best['spec_hops']} handoffs {best.get('deep_handoffs', 0)} lookaheads_used {best.get('lookaheads_used', 0)}", flush=True)
+              f"searches {best['beam_searches']} hops {best['hops']} spec_searches {best['spec_searches']} spec_hops {best['spec_hops']} handoffs {best.get('deep_handoffs', 0)} lookaheads_used {best.get('lookaheads_used', 0)} big_searches {best.get('big_searches', 0)} big_hops {best.get('big_hops', 0)} packet_hops {best.get('packet_hops', 0)} own_scorings {best.get('own_scorings', 0)} prefetched {best.get('prefetched_hops', 0)} poll_timeouts {best.get('poll_timeouts', 0)}", flush=True)
         if os.environ.get("PROBE_COMPARE"):
             ref_rows = (ids_t.clone(), dist_t.clone()); ref_c = dict(c)
             for envs in ({"WANN_NO_BIG": "1"}, {"WANN_NO_SPEC": "1"}, {"WANN_NO_POLLERS": "1"}, {}):

@@ -16,5 +16,7 @@ for nq in NQS:
         os.environ["WANN_PROFILE_PHASES"] = "1"
         ids, dists, sizes, hops, cmps = wa.raw_beam_search(0, X, rows, 0, Q, qids, beam)
         os.environ.pop("WANN_PROFILE_PHASES")
+        os.environ["WANN_VERBOSE"] = "1"
         t0 = time.time(); wa.raw_beam_search(0, X, rows, 0, Q, qids, beam); t1 = time.time() - t0
+        os.environ.pop("WANN_VERBOSE")
         print(f"nq={nq} beam={beam}: hops/search {hops.mean():.1f} cmps/search {cmps.mean():.0f} call {t1*1e3:.1f} ms", flush=True)

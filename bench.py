@@ -77,6 +77,28 @@ def make_data(n, d, nq, draws=1):
     return X, Q, labels
 
 
+def make_data_deep(n, d, nq, draws=1):
+    """BASELINE.json configs[3] ("deep-10M-like": unit-norm mixture rows, inner product) -- the law and seeds of
+    tools/bench_configs.py --config deep."""
+    import numpy as np
+    from util import unit_mixture
+    g = unit_mixture(n, d, 2025)
+    X = g(n)
+    Q = np.concatenate([g(nq) for _ in range(max(1, draws))])
+    labels = ((np.random.default_rng(77).permutation(n) + 0.5) / n).astype(np.float32)
+    return X, Q, labels
+
+
+# --workload: what a step searches.  "sift" = BASELINE.json configs[1] (the metric's configuration); "deep" = configs[3], the
+# workload the baseline names for the 8-GPU run (the same launcher, sharding and all-gather).
+WORKLOADS = {
+    "sift": dict(make=make_data, n=1_000_000, d=128, metric="l2", cls="VamanaRangeFilterTreeIndexFloatEuclidian", cutoff=1000, split=2,
+                 R=64, L=500, alpha=1.0, method="optimized_postfilter", label="SIFT-1M-like", dist="L2", cache="siftlike", shared_cache=False),
+    "deep": dict(make=make_data_deep, n=9_990_000, d=96, metric="mips", cls="VamanaRangeFilterTreeIndexFloatMips", cutoff=1000, split=4,
+                 R=64, L=500, alpha=1.0, method="optimized_postfilter", label="deep-10M-like", dist="MIPS", cache="deeplike", shared_cache=True),
+}
+
+
 def make_windows(labels_sorted, nq, p, seed):
     import numpy as np
     rng = np.random.default_rng(seed)
@@ -95,14 +117,14 @@ def make_windows(labels_sorted, nq, p, seed):
 
 
 def ground_truth(torch, Xt, x2, labt, Qt, Wt, k):
-    """Exact filtered top-k on the GPU (integer-valued data: fp32 arithmetic is exact)."""
+    """Exact filtered top-k on the GPU (integer-valued data: fp32 arithmetic is exact).  x2 = None: inner-product distance."""
     nq = Qt.shape[0]
     out = torch.empty((nq, k), dtype=torch.int64, device=Xt.device)
     cnt = torch.empty((nq,), dtype=torch.int64, device=Xt.device)
-    step = 256
+    step = max(16, min(256, int(2**31 // (4 * Xt.shape[0]))))
     for a in range(0, nq, step):
         q = Qt[a:a + step]
-        dmat = x2[None, :] - 2.0 * (q @ Xt.T) + (q * q).sum(1, keepdim=True)
+        dmat = -(q @ Xt.T) if x2 is None else x2[None, :] - 2.0 * (q @ Xt.T) + (q * q).sum(1, keepdim=True)
         mask = (labt[None, :] >= Wt[a:a + step, 0:1]) & (labt[None, :] <= Wt[a:a + step, 1:2])
         dmat.masked_fill_(~mask, float("inf"))
         vals, idx = torch.topk(dmat, k, dim=1, largest=False)
@@ -167,18 +189,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --nq queries per GPU; strong: ONE --nq-query batch cut across the GPUs")
-    ap.add_argument("--n", "--points", dest="n", type=int, default=1_000_000)  # (--points: "--n" is an ambiguous prefix for torch.distributed.run)
+    ap.add_argument("--workload", choices=tuple(WORKLOADS), default="sift",
+                    help="sift = BASELINE.json configs[1] (the metric's configuration); deep = configs[3] (deep-10M-like, 4-ary tree, inner product)")
+    ap.add_argument("--n", "--points", dest="n", type=int, default=0)  # (--points: "--n" is an ambiguous prefix for torch.distributed.run)
     ap.add_argument("--nq", type=int, default=10_000)
-    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--fraction", type=int, default=-3, help="headline window fraction exponent")
-    ap.add_argument("--fractions", default="all", help="'all' = also sweep 2^-16..2^0 (N=1), 'headline' = skip, or a list of exponents '-9,-6'")
+    ap.add_argument("--fractions", default=None, help="'all' = also sweep 2^-16..2^0 (N=1; default for sift), 'headline' = skip, or a list of exponents '-9,-6'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
-    ap.add_argument("--configs", default="all", help="N=1: the other BASELINE.json configurations as extra legs of the line: 'all' = glove "
+    ap.add_argument("--configs", default=None, help="N=1: the other BASELINE.json configurations as extra legs of the line: 'all' = glove "
                     "(configs[2]), deep (configs[3] on this one GPU), adverse (configs[4]); 'none'; or a comma list")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.n = args.n or wl["n"]
+    args.dim = args.dim or wl["d"]
+    if args.fractions is None:
+        args.fractions = "all" if args.workload == "sift" else "headline"
+    if args.configs is None:
+        args.configs = "all" if args.workload == "sift" else "none"
 
     # ---- N > 1 without a launcher: start the ranks ourselves, BEFORE torch / HIP are touched in this process
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -214,23 +245,33 @@ def main():
     gnq = args.nq * draws                      # the job's batch
     lo, hi = shard_bounds(gnq, world, rank)    # this rank's shard (global query numbers)
     nq = hi - lo
-    R, L, alpha, cutoff, split = 64, 500, 1.0, 1000, 2
+    R, L, alpha, cutoff, split = wl["R"], wl["L"], wl["alpha"], wl["cutoff"], wl["split"]
+    method = wl["method"]
     t0 = time.time()
-    X, Qg, labels = make_data(n, d, args.nq, draws)
+    X, Qg, labels = wl["make"](n, d, args.nq, draws)
     log(f"data n={n} d={d} batch={gnq} ({args.scaling} scaling, {world} rank(s)) in {time.time() - t0:.1f}s; host cpus={ncpu}")
 
-    cache = os.path.join(args.cache, f"siftlike_n{n}_d{d}_R{R}_L{L}_c{cutoff}_s{split}") + "/"
+    cache = os.path.join(args.cache, f"{wl['cache']}_n{n}_d{d}_R{R}_L{L}_c{cutoff}_s{split}") + "/"
     os.makedirs(cache, exist_ok=True)
     bp = wa.BuildParams(R, L, alpha, cache)
     t0 = time.time()
-    if world > 1:  # every rank builds its replica on its own GPU (seconds); no shared cache files
-        bp = wa.BuildParams(R, L, alpha, "")
-    index = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=cutoff, split_factor=split, build_params=bp)
+    make_index = lambda params: getattr(wa, wl["cls"])(X, labels, cutoff=cutoff, split_factor=split, build_params=params)  # noqa: E731
+    if world > 1 and wl["shared_cache"]:
+        # a big index (deep: 21 845 graphs, two minutes on one GPU): rank 0 builds it once into the shared graph cache
+        # (the reference's file format), the other ranks load the files -- not N concurrent builds
+        index = make_index(bp) if rank == 0 else None
+        dist.barrier()
+        if rank != 0:
+            index = make_index(bp)
+    elif world > 1:  # every rank builds its replica on its own GPU (seconds); no shared cache files
+        index = make_index(wa.BuildParams(R, L, alpha, ""))
+    else:
+        index = make_index(bp)
     build_s = time.time() - t0
     log(f"index ready in {build_s:.1f}s: levels {index.levels()}, {index.device_bytes() / 2**30:.2f} GiB in HBM")
 
     Xt = torch.from_numpy(X).to(dev)
-    x2 = (Xt * Xt).sum(1)
+    x2 = (Xt * Xt).sum(1) if wl["metric"] == "l2" else None
     labt = torch.from_numpy(labels).to(dev)
     Qgt = torch.from_numpy(Qg).to(dev)         # the whole batch on every rank (sharded_batch_search's contract)
     Q, Qt = Qg[lo:hi], Qgt[lo:hi]
@@ -247,7 +288,7 @@ def main():
 
     def run(Wt, beam, mult):
         """this rank's shard through the device-pointer C-ABI entry point"""
-        index.batch_search_device(Qt.data_ptr(), Wt.data_ptr(), nq, lo, "optimized_postfilter", qparams(wa, beam, mult),
+        index.batch_search_device(Qt.data_ptr(), Wt.data_ptr(), nq, lo, method, qparams(wa, beam, mult),
                                   ids_t.data_ptr(), dist_t.data_ptr(), 0)
 
     def sweep(p, seed):
@@ -273,9 +314,12 @@ def main():
                 rows.append(dict(beam=beam, mult=mult, recall=rec, wall_ms=wall * 1e3, device_ms=c["device_ms"]))
                 if rec > 0.95 and (best_ok is None or wall * 1e3 < best_ok):
                     best_ok = wall * 1e3
-                if rec > 0.999 or (prev is not None and rec <= prev and mult != 1):
+                scans_only = c["beam_searches"] == 0 and c["brute_rows"] > 0
+                if scans_only or rec > 0.999 or (prev is not None and rec <= prev and mult != 1):
                     break
                 prev = rec
+            if scans_only:  # every window of this fraction takes the exact scan: beam and multiplier change nothing -- one setting
+                break
             first = next(r for r in rows if r["beam"] == beam and r["mult"] == 1)
             if best_ok is not None and first["wall_ms"] > 3 * best_ok:
                 break
@@ -306,15 +350,17 @@ def main():
     agg = dict(beam_searches=0, hops=0, dist_cmps=0, label_reads=0, brute_rows=0, search_kernel_ms=0.0, device_ms=0.0, rounds=0)
     qp_run = qparams(wa, beam, mult)
 
-    def search_fn(q, r, base):
-        """local search of one shard: (nq_shard, d) / (nq_shard, 2) device tensors, global number of its first query"""
+    def search_fn(q, r, base, out_ids=None, out_dists=None):
+        """local search of one shard: (nq_shard, d) / (nq_shard, 2) device tensors, global number of its first query; the rows
+        go straight into the buffers the caller hands over (the all-gather's send planes)"""
         m = q.shape[0]
-        index.batch_search_device(q.data_ptr(), r.data_ptr(), m, base, "optimized_postfilter", qp_run,
-                                  ids_t.data_ptr(), dist_t.data_ptr(), 0)
+        oi = ids_t[:m] if out_ids is None else out_ids
+        od = dist_t[:m] if out_dists is None else out_dists
+        index.batch_search_device(q.data_ptr(), r.data_ptr(), m, base, method, qp_run, oi.data_ptr(), od.data_ptr(), 0)
         c = index.counters()
         for kk in agg:
             agg[kk] += c[kk]
-        return ids_t[:m], dist_t[:m]
+        return oi, od
 
     def step():
         # query shards -> HIP batch_search on this rank's GPU -> ONE all-gather of the per-shard top-k over RCCL/xGMI
@@ -357,10 +403,10 @@ def main():
     host_ms = None
     if rank == 0 and world == 1:
         Wn = W.astype(np.float32)
-        index.batch_search(Q, Wn, nq, "optimized_postfilter", qparams(wa, beam, mult))
+        index.batch_search(Q, Wn, nq, method, qparams(wa, beam, mult))
         t1 = time.perf_counter()
         for _ in range(5):
-            index.batch_search(Q, Wn, nq, "optimized_postfilter", qparams(wa, beam, mult))
+            index.batch_search(Q, Wn, nq, method, qparams(wa, beam, mult))
         host_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     # B = 4(R+1)*hops + d*sizeof(T)*dist_cmps + 4*|beam_out|  per search.  N > 1: bytes of ALL ranks over
@@ -390,7 +436,7 @@ def main():
         "metric": "QPS @ recall@10>=0.95, window fraction 2^%d" % args.fraction, "value": round(qps, 1), "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SIFT-1M-like n={n} d={d} L2, 2-WST (cutoff {cutoff}, R={R}, L={L}, alpha={alpha}) optimized_postfilter, "
+        "config": {"workload": f"{wl['label']} n={n} d={d} {wl['dist']}, {split}-WST (cutoff {cutoff}, R={R}, L={L}, alpha={alpha}) {method}, "
                                f"window 2^{args.fraction}, {gnq} queries per step ({nq} on rank 0), k={K}",
                    "beam": beam, "final_beam_multiply": mult, "recall_at_10": round(final_recall, 4),
                    "build_s": round(build_s, 1), "index_gib": round(index.device_bytes() / 2**30, 2),
@@ -401,26 +447,54 @@ def main():
         "roofline": roofline,
     }
 
-    # ---- CPU baseline: the REAL reference on this box's host cores, same graphs, same batch, same setting
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            result["cpu_baseline"] = cpu_baseline(np, X, Q, labels, W, nq, beam, mult, cache, (R, L, alpha, cutoff, split),
-                                                  all_ids.cpu().numpy().view(np.uint32), all_d.cpu().numpy(), qparams)
-        except Exception as e:  # never lose the GPU number to a baseline problem
-            log("cpu baseline failed:", repr(e))
-            result["cpu_baseline"] = None
+    # ---- legs for the REAL reference (same graph files, same batches): the headline fraction at the GPU's setting and at the
+    #      cheapest settings that reach recall 0.95 (the reference's own best setting need not be the GPU's), then every
+    #      window fraction at its best setting.  GPU rows are kept per leg: the reference's must be identical.
+    legs = {}
+
+    def add_leg(name, Wn, b_, m_, ids_np, d_np):
+        legs["W|" + name] = np.asarray(Wn, dtype=np.float32)
+        legs["set|" + name] = np.array([b_, m_], dtype=np.int64)
+        legs["ids|" + name] = ids_np
+        legs["dists|" + name] = d_np
+
+    want_ref = rank == 0 and world == 1 and not args.no_cpu_baseline
+    head_names = []
+    if want_ref:
+        add_leg(f"h:{beam},{mult}", W, beam, mult, all_ids.cpu().numpy().view(np.uint32), all_d.cpu().numpy())
+        head_names.append(f"h:{beam},{mult}")
+        ok_rows = sorted((r for r in rows if r["recall"] > 0.95), key=lambda r: (r["beam"] * (1 + (r["mult"] if r["mult"] > 1 else 0)), r["beam"]))
+        for r in ok_rows[:3]:
+            nm = f"h:{r['beam']},{r['mult']}"
+            if nm not in head_names:
+                run(Wt, r["beam"], r["mult"])
+                add_leg(nm, W, r["beam"], r["mult"], ids_t.cpu().numpy().view(np.uint32).copy(), dist_t.cpu().numpy().copy())
+                head_names.append(nm)
 
     # ---- all 17 window fractions (configs[1]), device-resident, best setting per fraction
+    per = None
     if rank == 0 and world == 1 and args.fractions != "headline":
         per = {}
         for p in (range(-16, 1) if args.fractions == "all" else [int(x) for x in args.fractions.split(",")]):
-            _, _, rws, b = sweep(p, 2000 + p)
-            if b is None:
+            Wp, Wpt, rws, b = sweep(p, 2000 + p)
+            meets = b is not None
+            if b is None:  # no setting of the sweep reaches recall 0.95 here (the reference does not either: same rows)
                 b = max(rws, key=lambda r: r["recall"])
             per[f"2^{p}"] = dict(qps=round(nq / b["wall_ms"] * 1e3, 1), recall=round(b["recall"], 4), beam=b["beam"], mult=b["mult"],
-                                 device_ms=round(b["device_ms"], 3))
+                                 device_ms=round(b["device_ms"], 3), meets_recall=meets, settings_swept=len(rws))
             log(f"  2^{p}: {per[f'2^{p}']}")
+            if want_ref:
+                run(Wpt[lo:hi], b["beam"], b["mult"])
+                add_leg(f"f:{p}", Wp[lo:hi], b["beam"], b["mult"], ids_t.cpu().numpy().view(np.uint32).copy(), dist_t.cpu().numpy().copy())
         result["per_fraction"] = per
+
+    # ---- CPU baseline: the REAL reference on this box's host cores
+    if want_ref:
+        try:
+            result["cpu_baseline"] = cpu_baseline(np, args.workload, n, d, nq, cache, legs, head_names, f"h:{beam},{mult}", per)
+        except Exception as e:  # never lose the GPU number to a baseline problem
+            log("cpu baseline failed:", repr(e))
+            result["cpu_baseline"] = None
 
     # ---- the other BASELINE.json configurations (parity cases at full size; each in a child process with its own index)
     if rank == 0 and world == 1 and args.configs != "none":
@@ -446,9 +520,8 @@ def other_configs(want, cache, ncpu):
     legs = {
         "glove": ("configs[2]", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "glove", "--threads", threads, "--seconds", "8",
                                  "--cache", os.path.join(cache, "cfg")]),
-        # the reference would need ~10 min to load 21 845 graph files and 10^7 points: its leg is tools/bench_configs.py --config deep --threads 32
-        "deep": ("configs[3] (one GPU)", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "deep", "--threads", "", "--cache",
-                                          os.path.join(cache, "cfg")]),
+        "deep": ("configs[3] (one GPU)", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "deep", "--threads", threads, "--seconds", "8",
+                                          "--cache", os.path.join(cache, "cfg")]),
         "adverse": ("configs[4]", [os.path.join(REPO, "tools", "bench_prefilter.py")]),
     }
     for name in want:
@@ -495,35 +568,60 @@ def measured_traffic(beam, mult, n, nq_per_gpu, fraction=-3):
     return best if best else (None, None)
 
 
-def cpu_baseline(np, X, Q, labels, W, nq, beam, mult, cache, params, gpu_ids, gpu_dists, qparams):
-    """The REAL reference on this box's host cores, same graphs / batch / setting.  The reference fixes its
-    thread count at first use, so every thread count is timed in its own process (tools/ref_baseline.py);
-    the best one is reported."""
+def cpu_baseline(np, workload, n, d, nq, cache, legs, head_names, gpu_leg, per):
+    """The REAL reference on this box's host cores, on the graph files this run left in the cache.  The reference fixes its
+    thread count at first use, so every thread count is its own process (tools/ref_legs.py): first the GPU's own setting at
+    several thread counts, then -- at the best count, in ONE process that loads the index once -- the other candidate
+    settings of the headline fraction and every window fraction's leg.  `value` = the reference's best QPS over the headline
+    settings with recall@10 > 0.95 (its own best setting, not necessarily the GPU's)."""
     import subprocess
     import tempfile
-    n, d = X.shape
     ncpu = os.cpu_count() or 1
     tmp = tempfile.mkdtemp(prefix="wann_bench_")
-    res_path = os.path.join(tmp, "gpu_result.npz")
-    np.savez(res_path, ids=gpu_ids, dists=gpu_dists, W=W)
+
+    def run_legs(names, threads, seconds):
+        path = os.path.join(tmp, f"legs_{threads}_{len(names)}.npz")
+        np.savez(path, **{k: v for k, v in legs.items() if k.split("|", 1)[1] in names})
+        cmd = [sys.executable, os.path.join(REPO, "tools", "ref_legs.py"), "--workload", workload, "--threads", str(threads), "--n", str(n),
+               "--nq", str(nq), "--dim", str(d), "--cache", cache, "--legs", path, "--seconds", str(seconds)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            raise RuntimeError((out.stderr or "")[-500:])
+        return json.loads(line[-1])
+
     tried = []
     for threads in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), max(1, ncpu // 8), max(1, ncpu // 16)}, reverse=True):
-        cmd = [sys.executable, os.path.join(REPO, "tools", "ref_baseline.py"), "--threads", str(threads), "--n", str(n), "--nq", str(nq),
-               "--dim", str(d), "--beam", str(beam), "--mult", str(mult), "--cache", cache, "--result", res_path]
         try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-            tried.append(json.loads(line))
+            r = run_legs([gpu_leg], threads, 4.0)
+            tried.append(dict(threads=threads, kind=r["_kind"], **r[gpu_leg]))
             log(f"cpu baseline: {tried[-1]}")
         except Exception as e:  # noqa: BLE001
             log(f"cpu baseline with {threads} threads failed: {e!r}")
     if not tried:
         return None
-    best = max(tried, key=lambda r: r["qps"])
-    return dict(value=round(best["qps"], 1), unit="queries/s", cores=best["threads"], kind=best["kind"],
-                sample=f"the same {nq}-query batch and (beam {beam}, x{mult}) setting, best of {best['reps']} batch_search calls, same graph files; "
-                       f"thread counts tried: " + ", ".join(f"{r['threads']} -> {r['qps']:.0f} QPS" for r in tried),
-                gpu_rows_identical_ids=best["same_ids"], gpu_rows_identical_dists=best["same_dists"])
+    best_t = max(tried, key=lambda r: r["qps"])
+    others = [nm for nm in legs_names(legs) if nm != gpu_leg]
+    rest = run_legs(others, best_t["threads"], 2.5) if others else {}
+    heads = {gpu_leg: dict(best_t)}
+    heads.update({nm: rest[nm] for nm in head_names if nm in rest})
+    top = max(heads.items(), key=lambda kv: kv[1]["qps"])
+    if per is not None:  # the reference beside every window fraction
+        for key, rec in per.items():
+            r = rest.get("f:" + key[2:])
+            if r:
+                rec.update(reference_qps=round(r["qps"], 1), reference_threads=best_t["threads"], rows_identical_dists=r["same_dists"],
+                           rows_identical_ids=r["same_ids"], rows_identical_id_sets=r["same_id_sets"])
+    return dict(value=round(top[1]["qps"], 1), unit="queries/s", cores=best_t["threads"], kind=best_t["kind"],
+                sample=f"the same {nq}-query batch, same graph files; best over the settings with recall@10 > 0.95 "
+                       f"({', '.join(nm[2:] + ' -> ' + format(v['qps'], '.0f') + ' QPS' for nm, v in heads.items())}; beam,multiplier) at the best of "
+                       f"{', '.join(str(r['threads']) + ' -> ' + format(r['qps'], '.0f') for r in tried)} threads (GPU's setting)",
+                setting=top[0][2:], gpu_setting=gpu_leg[2:], value_at_gpu_setting=round(best_t["qps"], 1),
+                gpu_rows_identical_ids=min(v["same_ids"] for v in heads.values()), gpu_rows_identical_dists=min(v["same_dists"] for v in heads.values()))
+
+
+def legs_names(legs):
+    return sorted({k.split("|", 1)[1] for k in legs if k.startswith("W|")})
 
 
 if __name__ == "__main__":

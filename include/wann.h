@@ -153,6 +153,12 @@ int wann_partition_graph(const wann_index *index, int64_t level, int64_t idx, in
                          int64_t max_degree);
 int64_t wann_max_degree(const wann_index *index);
 int64_t wann_device_bytes(const wann_index *index);
+/* In-process multi-device mode: with WANN_DEVICES=a,b,... in the environment wann_index_create makes the index resident on
+ * every listed device (a device may be listed twice) and wann_batch_search -- the host-buffer call, the reference's boundary
+ * (src/range_filter_tree.h:62-96: one call parallelises over all queries) -- cuts its batch into contiguous shards, one host
+ * thread + stream per replica; queries keep their global row numbers.  wann_batch_search_device serves the primary only.
+ * Returns the number of replicas (1 without WANN_DEVICES). */
+int wann_num_replicas(const wann_index *index);
 
 /* Graph-cache tool: build (host, multi-threaded) and save only the cache files of the
  * partitions p with p % nshards == shard, without creating a device index.  Used to split the

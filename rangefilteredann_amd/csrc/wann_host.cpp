@@ -16,6 +16,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wann.h"
@@ -128,6 +129,12 @@ struct Workspace {
 
 struct wann_index {
   HostIndex H;
+  // WANN_DEVICES (in-process multi-device mode): further replicas of the device index, one per extra device listed; a replica
+  // shares the primary's host index
+  HostIndex *Hp = nullptr;
+  HostIndex &host() { return Hp ? *Hp : H; }
+  const HostIndex &host() const { return Hp ? *Hp : H; }
+  std::vector<std::unique_ptr<wann_index>> replicas;
   int device = 0;
   int dtype = WANN_DTYPE_F32;  // element type of the caller's points / host queries (device rows are fp32)
   int num_cus = 256;
@@ -163,7 +170,7 @@ struct wann_index {
 namespace {
 
 void upload_index(wann_index &I) {
-  HostIndex &H = I.H;
+  HostIndex &H = I.host();
   const BuildSpec &s = H.spec;
   HIP_CHECK(hipSetDevice(I.device));
   hipDeviceProp_t prop;
@@ -316,17 +323,18 @@ struct RoundCfg {
 // legacy: the one-wave kernel that holds the first-generation cores (k_search<., 2>: dev switches, the cut step); it is also
 // what a beam that does not fit the LDS next to the helper waves' mailbox gets.  The production one-wave kernel
 // (k_search<., 1>) always keeps its seen-filter in global memory.
+// base_pool: the four-wave kernel's per-wave pool (kSearchPoolBytes, or lean_pool_bytes() for three workgroups per CU).
 RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false,
-                    bool legacy = false) {
+                    bool legacy = false, int base_pool = kSearchPoolBytes) {
   RoundCfg rc{};
   const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
-  if (cap_bytes > kSearchPoolBytes) big_lds = true;
+  if (cap_bytes > base_pool) big_lds = true;
   const int wpb = big_lds ? 1 : kWavesPerBlock;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
   if (big_lds && !legacy && cap_bytes + 4096 + kScoreBoxBytes > 150 * 1024 - common) legacy = true;
   const int box_bytes = (big_lds && !legacy) ? kScoreBoxBytes : 0;
   if (big_lds && !legacy) force_table = true;
-  int pool = kSearchPoolBytes;
+  int pool = base_pool;
   // (one-wave kernels: + the clash-detection scratch beside the largest beam; production kernel: + the helper waves' mailbox
   // at the end of the pool -- the kernel takes kScoreBoxBytes off whenever it runs with helpers, so the decisions below use
   // what is left)
@@ -336,7 +344,10 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   const int per_block = (common + pool) * wpb;
   if (per_block > 160 * 1024) throw std::runtime_error("beam-search LDS footprint exceeds 160 KiB");
   // register budget: the L2 kernel holds two whole 512-B rows per lane pair in flight (2 waves/SIMD)
-  int blocks_per_cu = std::min((I.view.metric == 1 ? 16 : 8) / wpb, (160 * 1024) / per_block);
+  // (four-wave kernel: the squared-L2 float kernel needs 232 registers: two waves per SIMD; the inner-product and byte-row
+  // kernels are built for three)
+  const int waves_per_cu = (I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32) ? 12 : 8;
+  int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, (160 * 1024) / per_block);
   blocks_per_cu = std::max(1, blocks_per_cu);
   if (const char *e = getenv("WANN_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(e)));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
@@ -356,6 +367,16 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   rc.big_lds = big_lds;
   rc.slots = rc.lc.blocks * wpb;
   return rc;
+}
+
+// Per-wave pool with which THREE four-wave workgroups share a CU's 160 KiB of LDS (inner-product / byte-row kernels, which
+// fit three waves per SIMD): the in-kernel cap's beam (10 KiB) still fits, the seen-filter of beams up to 90 too.  0: this
+// index can not use it (rows too long).
+int lean_pool_bytes(const wann_index &I) {
+  if (!(I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32)) return 0;
+  const int common = search_lds_bytes_per_wave(I.view.stride, 0);
+  const int pool = (((160 * 1024) / 3) / kWavesPerBlock - common) & ~63;
+  return pool >= kInKernelBeamCap * 8 + 1536 ? pool : 0;
 }
 
 int method_code(const char *m) {
@@ -453,19 +474,19 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
                const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st) {
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
   // the brute-force classes ignore the beam (the reference driver passes beam_size = 0 there, run_our_method.py:256)
-  if (qp.beam_width <= 0 && I.H.vamana_leaves) throw std::runtime_error("beam_width must be positive");
+  if (qp.beam_width <= 0 && I.host().vamana_leaves) throw std::runtime_error("beam_width must be positive");
   if (qp.postfiltering_max_beam > (1 << 20)) throw std::runtime_error("postfiltering_max_beam too large");
   HIP_CHECK(hipSetDevice(I.device));
   Workspace &W = I.ws;
   const int k = (int)qp.k;
   const int mcode = method_code(method);
-  const bool tree = I.H.spec.kind == WANN_KIND_TREE_PREFILTER || I.H.spec.kind == WANN_KIND_TREE_VAMANA;
+  const bool tree = I.host().spec.kind == WANN_KIND_TREE_PREFILTER || I.host().spec.kind == WANN_KIND_TREE_VAMANA;
   // fenwick / three_split cover a window with several buckets (+ two brute-forced ends)
   // (optimized_postfilter needs one slot unless its tiny-window / ratio fallback reaches the
   // multi-bucket fenwick cover, which cannot happen for split <= 4 without a ratio: SURVEY.md A.5)
-  const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.H.spec.split_factor <= 4);
+  const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.host().spec.split_factor <= 4);
   const int maxt = single ? 1 : 96;
-  const bool spec = I.H.vamana_leaves && !getenv("WANN_NO_SPEC");
+  const bool spec = I.host().vamana_leaves && !getenv("WANN_NO_SPEC");
   const int64_t sub_slots = spec ? std::min<int64_t>(nq * (int64_t)maxt * 4 + 1024, (int64_t)1 << 26) : 0;
   W.ensure(nq, k, maxt, sub_slots);
   if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
@@ -526,16 +547,16 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
   // the list sizes come back while the exact scans run: the beam-search launches are sized by them, and skipped
   // altogether for batches without graph tasks (tiny windows) / without levels beyond the in-kernel cap
-  const bool sized = I.H.vamana_leaves && qp.beam_width < qp.postfiltering_max_beam;
+  const bool sized = I.host().vamana_leaves && qp.beam_width < qp.postfiltering_max_beam;
   if (sized) {
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(W.ev_route, st));
   }
 
-  if (I.H.spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.H.spec.dtype == WANN_DTYPE_F32 && !getenv("WANN_NO_GEMM"))
+  if (I.host().spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.host().spec.dtype == WANN_DTYPE_F32 && !getenv("WANN_NO_GEMM"))
     dense_prefilter(I, d_queries, nq, k, st);
 
-  const bool may_brute = I.H.spec.kind != WANN_KIND_POSTFILTER && I.H.spec.kind != WANN_KIND_SUPER;
+  const bool may_brute = I.host().spec.kind != WANN_KIND_POSTFILTER && I.host().spec.kind != WANN_KIND_SUPER;
   if (may_brute) {
     BruteArgs ba{};
     ba.ix = I.view;
@@ -618,8 +639,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
     // (idle pollers look for chains that will outgrow their speculated levels: on unless WANN_SCAN=0)
     const bool scan_on = spec && !(getenv("WANN_SCAN") && atoi(getenv("WANN_SCAN")) == 0) && !getenv("WANN_NO_LOOKAHEAD");
-    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0) {
-      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0, a.old_general != 0);
+    auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0,
+                      int base_pool = kSearchPoolBytes) {
+      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0, a.old_general != 0, base_pool);
       big_lds = rc.big_lds;
       a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
       a.helper = (rc.lc.big == 1 && !getenv("WANN_NO_HELPER")) ? kHelpers : 0;
@@ -756,7 +778,11 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && graph_n * b0 >= deep_min * 150 &&
         !getenv("WANN_NO_DEEP") && std::max<int64_t>(4 * b0, 256) <= cap1)
       deep = getenv("WANN_DEEP_POLLERS") ? std::max(1, atoi(getenv("WANN_DEEP_POLLERS"))) : 4;
-    launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue || deep > 0) ? big_cap : 0, deep);
+    // Three workgroups per CU (a leaner LDS pool) where the kernel allows it and no companion workgroup has to share a CU with
+    // the ordinary ones (the deep-chain pollers book whole CUs of their own)
+    int base_pool = kSearchPoolBytes;
+    if (big_n == 0 && !may_continue && !getenv("WANN_NO_LEAN") && cap1 == kInKernelBeamCap && lean_pool_bytes(I) > 0) base_pool = lean_pool_bytes(I);
+    launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue || deep > 0) ? big_cap : 0, deep, base_pool);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int next_n = W.h_ints[I_NEXT0];
@@ -864,10 +890,10 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   fa.out_cnt = W.out_cnt.p;
   fa.nq = nq;
   fa.k = k;
-  fa.decode = I.H.sorted ? 1 : 0;
+  fa.decode = I.host().sorted ? 1 : 0;
   // padding ids: tree classes 0 (range_filter_tree.h:90), stand-alone post filter -1
   // (postfilter_vamana.h:212); PrefilterIndex reads past its result there (UB) -> defined as -1
-  fa.pad_id = I.H.sorted ? 0u : 0xFFFFFFFFu;
+  fa.pad_id = I.host().sorted ? 0u : 0xFFFFFFFFu;
   fa.ids = d_ids;
   fa.dists = d_dists;
   if (launch_finalize(fa, st)) throw HipError(std::string("k_finalize: ") + launch_last_error());
@@ -1017,8 +1043,43 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
     I->H.spec = make_spec(kind, metric, dtype, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
     std::vector<HostPart *> pending;
     build_host_index(I->H, points, labels, -1, 0, &pending);
+    // WANN_DEVICES=a,b,...: the index is replicated on every listed device and wann_batch_search (host buffers) cuts its batch
+    // into contiguous shards, one per replica.  `device` is the primary if it is listed, else the first entry is.
+    std::vector<int> extra;
+    if (const char *dv = getenv("WANN_DEVICES")) {
+      std::vector<int> list;
+      for (const char *c = dv; *c;) {
+        char *end = nullptr;
+        const long v = strtol(c, &end, 10);
+        if (end == c) break;
+        list.push_back((int)v);
+        c = (*end == ',') ? end + 1 : end;
+      }
+      for (int v : list)
+        if (v < 0 || v >= usable_devices()) throw std::runtime_error("WANN_DEVICES names device " + std::to_string(v) + ", which does not exist");
+      if (!list.empty()) {
+        size_t prim = 0;
+        for (size_t i = 0; i < list.size(); i++)
+          if (list[i] == device) {
+            prim = i;
+            break;
+          }
+        I->device = list[prim];
+        for (size_t i = 0; i < list.size(); i++)
+          if (i != prim) extra.push_back(list[i]);
+      }
+    }
     upload_index(*I);
     if (!pending.empty()) build_pending(*I, pending);
+    for (int dv : extra) {  // (after the build: the graphs are in the host index by now)
+      std::unique_ptr<wann_index> R(new wann_index);
+      R->Hp = &I->H;
+      R->device = dv;
+      R->dtype = dtype;
+      upload_index(*R);
+      I->replicas.push_back(std::move(R));
+    }
+    HIP_CHECK(hipSetDevice(I->device));
   } catch (HipError &e) {
     fail(WANN_ERR_HIP, e.what());
     return nullptr;
@@ -1049,41 +1110,110 @@ int wann_batch_search_device(wann_index *I, const void *d_queries, const float *
   return WANN_OK;
 }
 
+namespace {
+// one replica's share of a host-buffer call: stage, search (queries keep their global numbers), copy back
+void search_host_one(wann_index &T, const void *queries, const float *ranges, int64_t nq, int64_t qid_base, const char *method,
+                     const wann_query_params &qp, uint32_t *ids, float *dists) {
+  std::lock_guard<std::mutex> lk(T.mu);
+  HIP_CHECK(hipSetDevice(T.device));
+  Workspace &W = T.ws;
+  const int64_t d = T.host().spec.d;
+  if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
+  W.q_stage.ensure((size_t)nq * d);
+  W.r_stage.ensure((size_t)nq * 2);
+  W.id_stage.ensure((size_t)nq * qp.k);
+  W.dist_stage.ensure((size_t)nq * qp.k);
+  hipStream_t st = T.own_stream;
+  std::vector<float> qf;  // host queries arrive in the index's element type
+  if (nq && T.dtype != WANN_DTYPE_F32) {
+    qf = bytes_to_float(T.dtype, queries, nq * d);
+    queries = qf.data();
+  }
+  if (nq) {
+    HIP_CHECK(hipMemcpyAsync(W.q_stage.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
+  }
+  run_batch(T, W.q_stage.p, W.r_stage.p, nq, qid_base, method, qp, W.id_stage.p, W.dist_stage.p, st);
+  if (nq) {
+    HIP_CHECK(hipMemcpyAsync(ids, W.id_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(dists, W.dist_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+}
+}  // namespace
+
 int wann_batch_search(wann_index *I, const void *queries, const float *ranges, int64_t nq, const char *method,
                       const wann_query_params *qp, uint32_t *ids, float *dists) {
   if (!I || !qp || nq < 0 || (nq > 0 && (!queries || !ranges || !ids || !dists)))
     return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search");
-  std::lock_guard<std::mutex> lk(I->mu);
-  try {
-    HIP_CHECK(hipSetDevice(I->device));
-    Workspace &W = I->ws;
-    const int64_t d = I->H.spec.d;
-    if (qp->k <= 0 || qp->k > 1024) throw std::runtime_error("k must be in [1, 1024]");
-    W.q_stage.ensure((size_t)nq * d);
-    W.r_stage.ensure((size_t)nq * 2);
-    W.id_stage.ensure((size_t)nq * qp->k);
-    W.dist_stage.ensure((size_t)nq * qp->k);
-    hipStream_t st = I->own_stream;
-    std::vector<float> qf;  // host queries arrive in the index's element type
-    if (nq && I->dtype != WANN_DTYPE_F32) {
-      qf = bytes_to_float(I->dtype, queries, nq * d);
-      queries = qf.data();
+  const int G = 1 + (int)I->replicas.size();
+  if (G == 1 || nq < G) {
+    try {
+      search_host_one(*I, queries, ranges, nq, 0, method, *qp, ids, dists);
+    } catch (HipError &e) {
+      return fail(WANN_ERR_HIP, e.what());
+    } catch (std::exception &e) {
+      return fail(WANN_ERR_INVALID, e.what());
     }
-    if (nq) {
-      HIP_CHECK(hipMemcpyAsync(W.q_stage.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
-    }
-    run_batch(*I, W.q_stage.p, W.r_stage.p, nq, 0, method, *qp, W.id_stage.p, W.dist_stage.p, st);
-    if (nq) {
-      HIP_CHECK(hipMemcpyAsync(ids, W.id_stage.p, (size_t)nq * qp->k * 4, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipMemcpyAsync(dists, W.dist_stage.p, (size_t)nq * qp->k * 4, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-    }
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
+    return WANN_OK;
   }
+  // In-process multi-device mode (WANN_DEVICES): contiguous shards that keep their global query numbers (the reference uses
+  // a query's row number as its own id, range_filter_tree.h:62-96 + beamSearch.h:128), one host thread and one stream per
+  // replica, rows land in the caller's arrays.
+  const int64_t d = I->H.spec.d, esz = I->dtype == WANN_DTYPE_F32 ? 4 : 1;
+  std::vector<std::thread> threads;
+  std::vector<int> codes((size_t)G, WANN_OK);
+  std::vector<std::string> errs((size_t)G);
+  for (int g = 0; g < G; g++) {
+    const int64_t base = nq / G, rem = nq % G;
+    const int64_t lo = g * base + std::min<int64_t>(g, rem), cnt = base + (g < rem ? 1 : 0);
+    wann_index *T = g == 0 ? I : I->replicas[(size_t)g - 1].get();
+    threads.emplace_back([=, &codes, &errs] {
+      try {
+        search_host_one(*T, (const char *)queries + lo * d * esz, ranges + 2 * lo, cnt, lo, method, *qp, ids + lo * qp->k, dists + lo * qp->k);
+      } catch (HipError &e) {
+        codes[(size_t)g] = WANN_ERR_HIP;
+        errs[(size_t)g] = e.what();
+      } catch (std::exception &e) {
+        codes[(size_t)g] = WANN_ERR_INVALID;
+        errs[(size_t)g] = e.what();
+      }
+    });
+  }
+  for (auto &t : threads) t.join();
+  (void)hipSetDevice(I->device);
+  for (int g = 0; g < G; g++)
+    if (codes[(size_t)g] != WANN_OK) return fail(codes[(size_t)g], "replica " + std::to_string(g) + ": " + errs[(size_t)g]);
+  // counters of the call: work summed over the replicas, times of the slowest one
+  wann_counters sum = I->last;
+  for (auto &R : I->replicas) {
+    const wann_counters &c = R->last;
+    sum.beam_searches += c.beam_searches;
+    sum.hops += c.hops;
+    sum.dist_cmps += c.dist_cmps;
+    sum.brute_rows += c.brute_rows;
+    sum.label_reads += c.label_reads;
+    sum.rounds = std::max(sum.rounds, c.rounds);
+    sum.spec_searches += c.spec_searches;
+    sum.spec_hops += c.spec_hops;
+    sum.spec_dist_cmps += c.spec_dist_cmps;
+    sum.gemm_queries += c.gemm_queries;
+    sum.gemm_unproven += c.gemm_unproven;
+    sum.gemm_rescued += c.gemm_rescued;
+    sum.recovered_continuations += c.recovered_continuations;
+    sum.deep_handoffs += c.deep_handoffs;
+    sum.lookaheads_used += c.lookaheads_used;
+    sum.lookaheads_issued += c.lookaheads_issued;
+    sum.big_searches += c.big_searches;
+    sum.big_hops += c.big_hops;
+    sum.packet_hops += c.packet_hops;
+    sum.own_scorings += c.own_scorings;
+    sum.prefetched_hops += c.prefetched_hops;
+    sum.poll_timeouts += c.poll_timeouts;
+    sum.device_ms = std::max(sum.device_ms, c.device_ms);
+    sum.search_kernel_ms = std::max(sum.search_kernel_ms, c.search_kernel_ms);
+  }
+  I->last = sum;
   return WANN_OK;
 }
 
@@ -1121,6 +1251,7 @@ int wann_partition_graph(const wann_index *I, int64_t level, int64_t idx, int32_
 }
 int64_t wann_max_degree(const wann_index *I) { return I ? I->H.spec.R : -1; }
 int64_t wann_device_bytes(const wann_index *I) { return I ? I->device_bytes : -1; }
+int wann_num_replicas(const wann_index *I) { return I ? 1 + (int)I->replicas.size() : -1; }
 
 int wann_build_cache_shard(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
                            const float *labels, int32_t cutoff, double split_factor, double shift_factor,

@@ -376,7 +376,9 @@ __device__ __forceinline__ void wave_touch_rows(const IndexView &ix, const int32
 
 // Distances of `cnt` rows whose (sorted-order) row numbers sit in ids_lds[0..cnt): afterwards lane
 // s < cnt holds the distance of row s.  scratch_lds: 64 floats.
-template <int METRIC, bool TWO_ROWS = true>
+// MIPS_TWO: the inner-product routine that keeps two rows per lane pair in flight (the exact scans: rows stream, registers
+// are plentiful there); the search kernels use the one-row routine (see below).
+template <int METRIC, bool TWO_ROWS = true, bool MIPS_TWO = false>
 __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32_t *ids_lds,
                                                 float *scratch_lds, const float *qv, int cnt,
                                                 int64_t row_off) {
@@ -398,29 +400,42 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
   }
 #endif
   if (METRIC == 1) {
+    // One row per lane pair and pass (up to two passes; the second pass's cache lines are requested before the first is
+    // scored).  Keeping two rows per pair in flight -- one round trip for up to 64 candidates -- costs 52 more registers, and
+    // the four-wave inner-product kernel runs three waves per SIMD (168 registers): more searches in flight beat the shorter
+    // first hops of each.
     const int h = lane & 1;
     const int np = (((ix.d + 3) >> 2) + 1) >> 1;  // wave-uniform
-    const int s0 = lane >> 1, s1 = 32 + (lane >> 1);
-    const bool act0 = s0 < cnt, act1 = s1 < cnt;
-    const int id0 = act0 ? ids_lds[s0] : 0, id1 = act1 ? ids_lds[s1] : 0;  // idle pairs score node 0: no branches
-    const float *p0 = ix.points + (row_off + id0) * (int64_t)ix.stride;
-    const float *p1 = ix.points + (row_off + id1) * (int64_t)ix.stride;
-    float d0, d1 = 0.f;
-    if (cnt > 32) {  // one round trip for up to 64 candidates
-      switch (np) {
-        case 12: mips_pair2_ct<12>(p0, p1, qv, ix.d, h, d0, d1); break;  // d = 96
-        case 13: mips_pair2_ct<13>(p0, p1, qv, ix.d, h, d0, d1); break;  // d = 100
-        default: d0 = mips_pair(p0, qv, ix.d, h); d1 = mips_pair(p1, qv, ix.d, h); break;
-      }
+    if (MIPS_TWO && cnt > 32 && (np == 12 || np == 13)) {  // one round trip for up to 64 rows
+      const int s0 = lane >> 1, s1 = 32 + (lane >> 1);
+      const bool act1 = s1 < cnt;
+      const int id0 = ids_lds[s0], id1 = act1 ? ids_lds[s1] : 0;
+      const float *p0 = ix.points + (row_off + id0) * (int64_t)ix.stride;
+      const float *p1 = ix.points + (row_off + id1) * (int64_t)ix.stride;
+      float d0, d1;
+      if (np == 12) mips_pair2_ct<12>(p0, p1, qv, ix.d, h, d0, d1);
+      else mips_pair2_ct<13>(p0, p1, qv, ix.d, h, d0, d1);
+      if (h) scratch_lds[s0] = d0;
       if (act1 && h) scratch_lds[s1] = d1;
-    } else {
-      switch (np) {
-        case 12: d0 = mips_pair_ct<12>(p0, qv, ix.d, h); break;
-        case 13: d0 = mips_pair_ct<13>(p0, qv, ix.d, h); break;
-        default: d0 = mips_pair(p0, qv, ix.d, h); break;
-      }
+      WAVE_SYNC();
+      float r = (lane < cnt) ? scratch_lds[lane] : 0.f;
+      WAVE_SYNC();
+      return r;
     }
-    if (act0 && h) scratch_lds[s0] = d0;
+    if (cnt > 32) wave_touch_rows(ix, ids_lds, 32, cnt - 32, row_off);
+    for (int base = 0; base < cnt; base += 32) {
+      const int s = base + (lane >> 1);
+      const bool act = s < cnt;
+      const int id = act ? ids_lds[s] : 0;  // idle pairs score node 0: no branches
+      const float *prow = ix.points + (row_off + id) * (int64_t)ix.stride;
+      float dd;
+      switch (np) {
+        case 12: dd = mips_pair_ct<12>(prow, qv, ix.d, h); break;  // d = 96
+        case 13: dd = mips_pair_ct<13>(prow, qv, ix.d, h); break;  // d = 100
+        default: dd = mips_pair(prow, qv, ix.d, h); break;
+      }
+      if (act && h) scratch_lds[s] = dd;
+    }
     WAVE_SYNC();
     float r = (lane < cnt) ? scratch_lds[lane] : 0.f;
     WAVE_SYNC();

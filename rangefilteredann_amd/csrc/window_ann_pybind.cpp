@@ -181,6 +181,7 @@ class Index {
     return rows;
   }
   int64_t device_bytes() const { return wann_device_bytes(h_); }
+  int num_replicas() const { return wann_num_replicas(h_); }
   int64_t num_points() const { return wann_num_points(h_); }
   int64_t dim() const { return wann_dim(h_); }
 
@@ -203,6 +204,7 @@ static void common_defs(py::class_<C> &c) {
       .def("partition_range", &C::partition_range)
       .def("partition_graph", &C::partition_graph, "level"_a, "idx"_a, "max_degree"_a)
       .def("device_bytes", &C::device_bytes)
+      .def("num_replicas", &C::num_replicas)
       .def("num_points", &C::num_points)
       .def("dim", &C::dim);
 }

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nq, out_dir):
+def _worker(rank, world, port, nq, out_dir, direct=False):
     import sys
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -37,7 +37,16 @@ def _worker(rank, world, port, nq, out_dir):
     qp = orc.QueryParams(10, 20)
     calls = []
 
-    def search_fn(q, r, base):
+    def search_plain(q, r, base):
+        return search_any(q, r, base)
+
+    def search_direct(q, r, base, out_ids, out_dists):  # (writes its rows into the all-gather's send planes)
+        ids, dists = search_any(q, r, base)
+        out_ids.copy_(ids)
+        out_dists.copy_(dists)
+        return out_ids, out_dists
+
+    def search_any(q, r, base):
         calls.append((int(base), q.shape[0]))
         # the oracle numbers queries from 0: emulate the global numbering by searching a padded batch
         full_q = np.zeros((base + q.shape[0], d), dtype=np.float32)
@@ -47,7 +56,7 @@ def _worker(rank, world, port, nq, out_dir):
         ids, dists = idx.batch_search(full_q, full_r, base + q.shape[0], "optimized_postfilter", qp)
         return torch.from_numpy(ids[base:].view(np.int32).copy()), torch.from_numpy(dists[base:].copy())
 
-    ids, dists = sharded_batch_search(search_fn, torch.from_numpy(Q), torch.from_numpy(W), 10)
+    ids, dists = sharded_batch_search(search_direct if direct else search_plain, torch.from_numpy(Q), torch.from_numpy(W), 10)
     lo, hi = shard_bounds(nq, world, rank)
     assert calls == [(lo, hi - lo)]
     eids, edists = idx.batch_search(Q, W, nq, "optimized_postfilter", qp)
@@ -56,10 +65,10 @@ def _worker(rank, world, port, nq, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nq", [64, 77])
-def test_two_rank_sharded_search_equals_single_process(oracle, tmp_path, nq):
+@pytest.mark.parametrize("nq,direct", [(64, False), (77, False), (64, True), (77, True)])
+def test_two_rank_sharded_search_equals_single_process(oracle, tmp_path, nq, direct):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), nq, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), nq, str(tmp_path), direct), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"ok{r}").read() == "1"
 

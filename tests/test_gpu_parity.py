@@ -644,6 +644,37 @@ def test_serialised_kernel_dispatch_is_survived(wa, gpu, tmp_path):
     assert int(outs["serial"]["rec"]) == 0  # pollers off: nothing to recover
 
 
+def test_in_process_multi_device_mode(wa, gpu, tmp_path, monkeypatch):
+    """WANN_DEVICES: the index is replicated per listed device and the host-buffer batch_search -- the call the reference's driver
+    makes (run_our_method.py unchanged) -- cuts its batch into contiguous shards with global query numbers.  On the one-GPU
+    box the list names device 0 twice (then three times, with an odd batch): rows and work counters equal the single call's."""
+    n, d, nq = 20000, 64, 777
+    g = sift_like(n, d, 21)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 22)
+    cache = str(tmp_path) + "/"
+    mk = lambda: wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=500, split_factor=2, build_params=wa.BuildParams(24, 48, 1.0, cache))  # noqa: E731
+    single = mk()
+    assert single.num_replicas() == 1
+    for devs in ("0,0", "0,0,0"):
+        monkeypatch.setenv("WANN_DEVICES", devs)
+        multi = mk()
+        monkeypatch.delenv("WANN_DEVICES")
+        assert multi.num_replicas() == len(devs.split(","))
+        for p, method, beam, mult in [(-3, "optimized_postfilter", 20, 2), (-8, "optimized_postfilter", 10, 1), (-5, "fenwick", 10, 1), (-12, "three_split", 10, 1)]:
+            W = windows(labels, nq, p, seed=33)
+            # (queries 0..nq-1 carry ids that name nodes of the root partition: the own-id skip must see GLOBAL numbers in every shard)
+            i1, d1 = single.batch_search(Q, W, nq, method, _qp(wa, beam, mult))
+            c1 = single.counters()
+            i2, d2 = multi.batch_search(Q, W, nq, method, _qp(wa, beam, mult))
+            c2 = multi.counters()
+            assert np.array_equal(d1, d2), (devs, p, method)
+            if method == "optimized_postfilter" and p > -12:
+                assert np.array_equal(i1, i2), (devs, p, method)
+            assert (c1["beam_searches"], c1["hops"], c1["dist_cmps"], c1["brute_rows"]) == (c2["beam_searches"], c2["hops"], c2["dist_cmps"], c2["brute_rows"]), (devs, p, method)
+        del multi
+
+
 def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
     """include/wann.h bound with ctypes exactly as INTEGRATION.md shows for a foreign host: create, search (host
     buffers), counters, destroy -- against the oracle."""

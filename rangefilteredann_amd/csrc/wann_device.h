@@ -92,6 +92,11 @@ struct RouteArgs {
   int32_t *qtask_cnt;  // [nq]
   int32_t *graph_list, *graph_count;
   int32_t *heavy_list, *heavy_count;  // graph tasks expected to need several doublings
+  // "evidence first": the SMALL speculated levels of tasks that also have levels in the companion launch are served before
+  // everything else (what they find tells early whether the task will outgrow its speculated levels); they are stored from
+  // the END of heavy_list downwards (heavy_cap entries), prio_count of them
+  int32_t *prio_count;
+  int32_t heavy_cap;
   int32_t *mid_list, *mid_count;      // graph tasks whose first beam may well fail (expected in-window entries < 4k): served second
   int32_t heavy_ratio;                // partition size / window size at or above which a task is heavy
   int32_t *risk_count;                // graph tasks whose predicted beam (k * partition / window) reaches half of cap_inkernel:
@@ -121,6 +126,8 @@ struct SearchArgs {
   const int32_t *list_count;
   const int32_t *heavy_list;   // served before `list` (may be null)
   const int32_t *heavy_count;
+  const int32_t *prio_count;   // entries stored from the end of heavy_list downwards, served first of all (may be null)
+  int32_t heavy_cap;
   const int32_t *mid_list;     // served between the two (may be null): a late doubling would be the tail of the launch
   const int32_t *mid_count;
   int32_t *cursor;
@@ -148,6 +155,7 @@ struct SearchArgs {
   int32_t old_general;          // dev / test: the first-generation general core (wave_beam_search) instead
   int32_t cut_k;                // raw mode, unfiltered VamanaIndex queries: QueryParams::k and ::cut of beamSearch.h:159-167
   double cut;                   //   (0: no cut step -- the post-filter path never takes it)
+  int32_t search_prio;          // one-wave kernel: the search wave raises its issue priority (s_setprio 3)
   int32_t helper;               // one-wave kernel: number of helper waves per workgroup (0 or kHelpers) that prepare row + distance
                                 // packets ahead of the search (score_helper)
   unsigned long long *g_beam;   // per wave slot beam, g_beam_cap entries each (or null)
@@ -195,6 +203,7 @@ struct SearchArgs {
   // slots la_base0 + [0, ...) below la_cap; chains at beams >= la_min_beam only.  nullptr = off.
   int32_t *la_count;
   int32_t la_base0, la_cap, la_min_beam;
+  int32_t scan_num;  // the scan asks for a look-ahead when the highest level is expected to find at most k * scan_num / 8 entries
   int32_t scan_tasks, scan_min_top;  // idle pollers scan task slots [0, scan_tasks) for speculating tasks that will need the
                                      // level after their highest one (highest beam >= scan_min_top); 0 = no scan
   int32_t la_found_max;  // a chain asks for a look-ahead when its last level found fewer in-window entries than this (0.4 k)

@@ -62,7 +62,7 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_POLL_WAITING = 146, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_POLL_WAITING = 146, I_PRIO_COUNT = 147, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
@@ -375,7 +375,9 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
 int lean_pool_bytes(const wann_index &I) {
   if (!(I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32)) return 0;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
-  const int pool = (((160 * 1024) / 3) / kWavesPerBlock - common) & ~63;
+  // (a workgroup's LDS is allocated in 1 KiB steps at most: 53 KiB per workgroup, three of them in 160 KiB)
+  int pool = (53 * 1024) / kWavesPerBlock - common;
+  if (const char *e = getenv("WANN_LEAN_POOL")) pool = atoi(e);  // dev knob
   return pool >= kInKernelBeamCap * 8 + 1536 ? pool : 0;
 }
 
@@ -517,6 +519,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.graph_count = W.ints.p + I_GRAPH_COUNT;
   ra.heavy_list = W.list_heavy.p;
   ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
+  ra.prio_count = getenv("WANN_NO_EVIDENCE_FIRST") ? nullptr : W.ints.p + I_PRIO_COUNT;
+  ra.heavy_cap = W.big_stride;
   ra.mid_list = W.list_mid.p;
   ra.mid_count = W.ints.p + I_MID_COUNT;
   ra.heavy_ratio = getenv("WANN_HEAVY_RATIO") ? atoi(getenv("WANN_HEAVY_RATIO")) : 8;
@@ -592,7 +596,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   int64_t graph_n = 0, big_n = 0, recovered = 0;
   if (sized) {
     HIP_CHECK(hipEventSynchronize(W.ev_route));
-    graph_n = (int64_t)W.h_ints[I_GRAPH_COUNT] + W.h_ints[I_HEAVY_COUNT] + W.h_ints[I_MID_COUNT];
+    graph_n = (int64_t)W.h_ints[I_GRAPH_COUNT] + W.h_ints[I_HEAVY_COUNT] + W.h_ints[I_MID_COUNT] + W.h_ints[I_PRIO_COUNT];
     big_n = (int64_t)W.h_ints[I_BIG_COUNT] + W.h_ints[I_BIG_COUNT + 1];
   }
   if (sized && graph_n + big_n > 0) {
@@ -608,6 +612,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.max_beam = (int32_t)qp.postfiltering_max_beam;
     sa.pool_bytes = kSearchPoolBytes;
     sa.force_general = getenv("WANN_FORCE_GENERAL") ? 1 : 0;
+    sa.search_prio = getenv("WANN_SEARCH_PRIO") ? atoi(getenv("WANN_SEARCH_PRIO")) : 0;  // dev knob
     sa.out_key = W.out_key.p;
     sa.out_cnt = W.out_cnt.p;
     sa.ctr = W.ctr.p;
@@ -703,6 +708,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
             if (deep_pollers == 0 && scan_on) {  // (companion mode: there are speculating tasks)
               big.scan_tasks = (int32_t)std::min<int64_t>(nq * maxt, INT32_MAX);
               big.scan_min_top = getenv("WANN_SCAN_MIN_TOP") ? atoi(getenv("WANN_SCAN_MIN_TOP")) : 2560;
+              big.scan_num = getenv("WANN_SCAN_NUM") ? atoi(getenv("WANN_SCAN_NUM")) : 16;
             }
             if (getenv("WANN_LA_EAGER")) {  // test hook: every chain that fails its second level asks for one
               a.la_min_beam = big.la_min_beam = (int32_t)(2 * first_beam);
@@ -761,6 +767,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.list_count = W.ints.p + I_GRAPH_COUNT;
     sa.heavy_list = W.list_heavy.p;
     sa.heavy_count = W.ints.p + I_HEAVY_COUNT;
+    sa.prio_count = W.ints.p + I_PRIO_COUNT;
+    sa.heavy_cap = W.big_stride;
     sa.mid_list = W.list_mid.p;
     sa.mid_count = W.ints.p + I_MID_COUNT;
     sa.cursor = W.ints.p + I_CURSOR0;
@@ -814,6 +822,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       sb.list_count = W.ints.p + I_NEXT0;
       sb.heavy_list = nullptr;
       sb.heavy_count = nullptr;
+      sb.prio_count = nullptr;
       sb.mid_list = nullptr;
       sb.mid_count = nullptr;
       sb.cursor = W.ints.p + I_CURSOR0 + 1;
@@ -845,6 +854,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         sf.list_count = W.ints.p + I_FINAL0 + 2 + g;
         sf.heavy_list = nullptr;
         sf.heavy_count = nullptr;
+        sf.prio_count = nullptr;
         sf.mid_list = nullptr;
         sf.mid_count = nullptr;
         sf.cursor = W.ints.p + I_CURSOR0 + 2 + g;

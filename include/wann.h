@@ -34,6 +34,7 @@ extern "C" {
 #endif
 
 #define WANN_ABI_VERSION 3
+#define WANN_MAX_DEGREE 64
 
 enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP = 3, WANN_ERR_IO = 4,
        WANN_ERR_UNSUPPORTED = 5 };
@@ -66,7 +67,10 @@ typedef struct {
 } wann_query_params;
 
 typedef struct {
-  int64_t max_degree;     /* R */
+  int64_t max_degree;     /* R; at most 64 (WANN_MAX_DEGREE): one adjacency row is one 64-lane load and one pass of the seen
+                           * filter per hop.  The reference accepts any R (types.h:77-112, graph.h:115-124); a larger one is
+                           * refused with WANN_ERR_UNSUPPORTED, never truncated.  Every shipped configuration of the reference's
+                           * driver uses R = 64 (run_our_method.py:28). */
   int64_t limit;          /* L (build beam) */
   double alpha;
   const char *cache_path; /* graph cache prefix, "" / NULL = none (postfilter_vamana.h:54-78,126-132) */

@@ -373,6 +373,211 @@ __global__ __launch_bounds__(256, 2) void k_gemm_scores(GemmArgs A) {
 #undef WANN_FETCH
 }
 
+// The same kernel for rows of 129 .. 512 floats (RedCaps: d = 512): the dimension is walked in SLABS slabs of 128 floats.
+// The A operand -- this wave's 32 query rows, split into bf16 pairs -- stays in registers for ALL slabs (8 SLABS k-steps:
+// 256 registers at 512 floats, hence one workgroup per CU and up to 512 registers per wave), the points are staged slab
+// by slab through the same LDS area and fetch pipeline, the accumulators run across the slabs of a step, and everything
+// after the MFMAs (selection network, hand-over format) is the narrow kernel's.  Columns beyond the row stride (a last,
+// partial slab) are zero on both sides.
+template <int SLABS>
+__global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const IndexView &ix = A.ix;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int W = 128;             // slab width in floats
+  constexpr int S = W / 16;          // MFMA k-steps per slab
+  constexpr int RB = 4 * W + 16;     // bytes per staged point and slab
+  unsigned char *Ps = smem;                                    // [128][RB]
+  float *base = reinterpret_cast<float *>(smem + 128 * RB);    // [128] per staged point: |p|^2 / 0
+  int *rid = reinterpret_cast<int *>(base + 128);              // [128] point rows of the step being fetched
+  // four slabs: the low halves of the LAST slab's A operand live in the LDS (8 KiB per wave; a lane reads its own 16 bytes):
+  // 32 registers that operands, accumulators and the block in flight do not have
+  constexpr int SR = SLABS == 4 ? 3 : SLABS;  // slabs whose low halves stay in registers
+  u32x4 *const alds = reinterpret_cast<u32x4 *>(smem + 128 * RB + 3 * 128 * 4) + wv * (S * 64) + lane;
+  constexpr int s4 = W >> 2, nit = s4 >> 1, nx = s4 >> 2;
+  const int half = lane >> 5, col = lane & 31;
+  const bool mips = ix.metric == 1;
+  const float scale = mips ? -1.f : -2.f;
+  const int ntiles = A.plan[P_NTILES], ng = A.plan[P_NGROUPS];
+  const int stride = ix.stride;
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int glo = 0, ghi = ng - 1;  // the last group whose first tile is <= t
+    while (glo < ghi) {
+      const int mid = (glo + ghi + 1) >> 1;
+      if (A.groups[mid].tile0 <= t) glo = mid;
+      else ghi = mid - 1;
+    }
+    const GemmGroup grp = A.groups[glo];
+    const int tl = t - grp.tile0, ch = tl / grp.nqt, q0 = (tl - ch * grp.nqt) << 7;
+    const int64_t w = grp.b - grp.a, wlast = w - 1;
+    const int64_t p_begin = (int64_t)ch * kGemmPointChunk;
+    const int64_t p_end = (p_begin + kGemmPointChunk < w) ? (p_begin + kGemmPointChunk) : w;
+    __syncthreads();  // the previous tile is done with the staging area
+    if (tid < 128) rid[tid] = ix.fi_sorted[grp.a + min(p_begin + tid, wlast)];
+    // A operand, slab by slab through the LDS (coalesced global loads): row 32 wv + col, columns 128 sl + 16 s + 8 half + (0..7)
+    u32x4 ah[S * SLABS], al[S * SR];
+    {
+      constexpr int DP = W + 4;
+      float *Qs = reinterpret_cast<float *>(Ps);
+      const int dlast = ix.d - 1;
+#pragma unroll
+      for (int sl = 0; sl < SLABS; sl++) {
+        if (sl) __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < nit; it++) {
+          const int idx = tid + it * 256;
+          const int r = idx / s4, c = W * sl + (idx - r * s4) * 4;
+          const bool live = q0 + r < grp.qcount;
+          const float *src = A.queries + (int64_t)A.gq[grp.qoff + (live ? q0 + r : grp.qcount - 1)] * ix.d;
+          f32x4 v;
+          v[0] = src[min(c + 0, dlast)]; v[1] = src[min(c + 1, dlast)]; v[2] = src[min(c + 2, dlast)]; v[3] = src[min(c + 3, dlast)];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = (live && c + e < ix.d) ? v[e] : 0.f;
+          *reinterpret_cast<f32x4 *>(Qs + r * DP + (c - W * sl)) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const float *qp = Qs + (32 * wv + col) * DP + 16 * s + 8 * half;
+          const f32x4 v0 = *reinterpret_cast<const f32x4 *>(qp), v1 = *reinterpret_cast<const f32x4 *>(qp + 4);
+          uint32_t h, l;
+          u32x4 lo4;
+          split2(v0[0], v0[1], h, l); ah[S * sl + s][0] = h; lo4[0] = l;
+          split2(v0[2], v0[3], h, l); ah[S * sl + s][1] = h; lo4[1] = l;
+          split2(v1[0], v1[1], h, l); ah[S * sl + s][2] = h; lo4[2] = l;
+          split2(v1[2], v1[3], h, l); ah[S * sl + s][3] = h; lo4[3] = l;
+          if (sl < SR) al[S * sl + s] = lo4;
+          else alds[s * 64] = lo4;
+        }
+      }
+    }
+    __syncthreads();
+    const int myrow = q0 + 32 * wv + col;
+    const bool live = myrow < grp.qcount;
+    const int64_t nsteps = (w + 127) >> 7;
+    f32x4 *erow = reinterpret_cast<f32x4 *>(A.scores + grp.soff) + ((int64_t)(live ? myrow : q0) * nsteps + (p_begin >> 7)) * 2 + half;
+    // fetch pipeline: the next (step, slab) travels HBM -> registers during the MFMAs of the current one.  `rid` holds the
+    // rows of the step being fetched; it moves on to the next step when a step's LAST slab is staged.
+    f32x4 pre[nit];
+    float pre_n = 0.f;
+    int pre_rid = 0;
+#define WANN_FETCHW(C0, SL, NEWSTEP)                                                                       \
+  {                                                                                                        \
+    _Pragma("unroll") for (int p = 0; p < 2; p++) {                                                        \
+      const float *src = ix.points + (int64_t)rid[64 * p + (tid >> 2)] * stride;                           \
+      _Pragma("unroll") for (int x = 0; x < nx; x++) {                                                     \
+        const int cf = W * (SL) + 4 * (tid & 3) + 16 * x;                                                  \
+        pre[p * nx + x] = *reinterpret_cast<const f32x4 *>(src + min(cf, stride - 4));                     \
+      }                                                                                                    \
+    }                                                                                                      \
+    if ((NEWSTEP) && tid < 128) {                                                                          \
+      pre_n = A.pnorm2[rid[tid]];                                                                          \
+      pre_rid = ix.fi_sorted[grp.a + min((C0) + 128 + tid, wlast)];                                        \
+    }                                                                                                      \
+  }
+    // (four slabs: the A operand alone is 256 registers -- the fetch is then NOT overlapped with the MFMAs: the 64 registers
+    // of a block in flight do not fit beside operands and accumulators)
+    constexpr bool PIPE = SLABS < 4;
+    if (PIPE) WANN_FETCHW(p_begin, 0, true)
+    f32x16 acc[4];
+    for (int64_t c0 = p_begin; c0 < p_end; c0 += 128) {
+#pragma unroll
+      for (int sl = 0; sl < SLABS; sl++) {
+        // (the barrier that ended the previous slab: nobody reads Ps / base / rid any more)
+        if (!PIPE && sl == 0 && tid < 128) {  // (rid = this step's rows; pre_rid = the next step's, taken over at the last slab)
+          pre_n = A.pnorm2[rid[tid]];
+          pre_rid = ix.fi_sorted[grp.a + min(c0 + 128 + tid, wlast)];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          if (!PIPE) {  // fetch and stage half a slab at a time: 32 registers in flight instead of 64
+            const float *src = ix.points + (int64_t)rid[64 * p + (tid >> 2)] * stride;
+#pragma unroll
+            for (int x = 0; x < nx; x++) pre[p * nx + x] = *reinterpret_cast<const f32x4 *>(src + min(W * sl + 4 * (tid & 3) + 16 * x, stride - 4));
+          }
+          unsigned char *dst = Ps + (64 * p + (tid >> 2)) * RB + 8 * (tid & 3);
+#pragma unroll
+          for (int x = 0; x < nx; x++) {
+            f32x4 v = pre[p * nx + x];
+            if (W * sl + 4 * (tid & 3) + 16 * x >= stride) v = f32x4{0.f, 0.f, 0.f, 0.f};  // beyond the row: zero
+            uint32_t h0, l0, h1, l1;
+            split2(v[0], v[1], h0, l0);
+            split2(v[2], v[3], h1, l1);
+            *reinterpret_cast<uint2 *>(dst + 32 * x) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(dst + 2 * W + 32 * x) = make_uint2(l0, l1);
+          }
+        }
+        if (tid < 128) {
+          if (sl == 0) base[tid] = (c0 + tid < p_end) ? (mips ? 0.f : pre_n) : kHuge;  // positions beyond the window never win
+          if (sl == SLABS - 1) rid[tid] = pre_rid;
+        }
+        __syncthreads();
+        if (PIPE) {
+          if (sl + 1 < SLABS) WANN_FETCHW(c0, sl + 1, false)
+          else WANN_FETCHW(c0 + 128, 0, true)  // unconditional (row numbers are clamped)
+        }
+        if (sl == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+        }
+        const unsigned char *pb = Ps + col * RB + 16 * half;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah[S * sl + s]);
+          const bf16x8 a_lo = __builtin_bit_cast(bf16x8, sl < SR ? al[S * sl + s] : alds[s * 64]);
+          // (one or two point tiles' operands at a time: registers are what this kernel is short of)
+          constexpr int JB = SLABS < 4 ? 2 : 1;
+#pragma unroll
+          for (int j0 = 0; j0 < 4; j0 += JB) {
+            bf16x8 bh[JB], bl[JB];
+#pragma unroll
+            for (int j = 0; j < JB; j++) {
+              bh[j] = *reinterpret_cast<const bf16x8 *>(pb + (j0 + j) * 32 * RB + 32 * s);
+              bl[j] = *reinterpret_cast<const bf16x8 *>(pb + (j0 + j) * 32 * RB + 2 * W + 32 * s);
+            }
+#pragma unroll
+            for (int j = 0; j < JB; j++) acc[j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], a_hi, acc[j0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < JB; j++) acc[j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a_lo, acc[j0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < JB; j++) acc[j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a_hi, acc[j0 + j], 0, 0, 0);
+          }
+        }
+        if (sl + 1 < SLABS) __syncthreads();  // every wave is done with this slab's rows
+      }
+      // the four smallest of this lane's 64 scores, sorted; low six mantissa bits = 16 j + reg (which position)
+      float m1 = kHuge, m2 = kHuge, m3 = kHuge, m4 = kHuge;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(base + 32 * j + 8 * g + 4 * half);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float sc = fmaf(scale, acc[j][4 * g + r], b4[r]);
+            float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
+            float a = fminf(m1, x);
+            x = fmaxf(m1, x);
+            m1 = a;
+            a = fminf(m2, x);
+            x = fmaxf(m2, x);
+            m2 = a;
+            a = fminf(m3, x);
+            x = fmaxf(m3, x);
+            m3 = a;
+            m4 = fminf(m4, x);
+          }
+        }
+      if (live) erow[(c0 - p_begin) >> 6] = f32x4{m1, m2, m3, m4};
+      __syncthreads();  // every wave is done with Ps / base / rid
+    }
+  }
+#undef WANN_FETCHW
+}
+
 // One wave per grouped query.  Its window's blocks each handed over their four smallest scores (sorted, position in
 // the low mantissa bits).  The first three of every block are candidates, the fourth bounds everything the block kept
 // to itself.  The kSelect best candidates live sorted in lanes 0 .. kSelect-1 (score bits in one register, window
@@ -568,11 +773,19 @@ int launch_group_windows(const GemmArgs &a, Counters *ctr, void *stream) {
 }
 
 int launch_gemm_scores(const GemmArgs &a, int num_cus, void *stream) {
-  const size_t lds = (size_t)128 * (4 * a.ix.stride + 16) + 3 * 128 * 4;
-  if (lds > 160 * 1024 || a.ix.stride > 128) {
-    g_gerr = "dimension too large for the dense prefilter tile";
-    return 1;
+  if (a.ix.stride > 128) {  // 129 .. 512 floats: slabs of 128, A operand in registers, one workgroup per CU
+    if (a.ix.stride > 512 || (a.ix.stride & 15)) {
+      g_gerr = "dimension too large for the dense prefilter tile";
+      return 1;
+    }
+    const int slabs = (a.ix.stride + 127) / 128;
+    const size_t ldsw = (size_t)128 * (4 * 128 + 16) + 3 * 128 * 4 + (slabs == 4 ? (size_t)4 * 8 * 64 * 16 : 0);
+    void (*kw)(GemmArgs) = slabs == 2 ? k_gemm_scores_wide<2> : slabs == 3 ? k_gemm_scores_wide<3> : k_gemm_scores_wide<4>;
+    if (gcheck(hipFuncSetAttribute((const void *)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw))) return 1;
+    hipLaunchKernelGGL(kw, dim3(num_cus > 0 ? num_cus : 256), dim3(256), ldsw, (hipStream_t)stream, a);
+    return gcheck(hipGetLastError());
   }
+  const size_t lds = (size_t)128 * (4 * a.ix.stride + 16) + 3 * 128 * 4;
   void (*kern)(GemmArgs) = nullptr;
   switch (a.ix.stride) {
     case 16: kern = k_gemm_scores<16>; break;

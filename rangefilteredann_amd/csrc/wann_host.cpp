@@ -394,7 +394,7 @@ int method_code(const char *m) {
 // never waits.
 void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, hipStream_t st) {
   Workspace &W = I.ws;
-  if (k > kSelect / 2 || I.view.stride > 128 || (I.view.stride & 15)) return;
+  if (k > kSelect / 2 || I.view.stride > 512 || (I.view.stride & 15)) return;  // (rows of up to 512 floats: RedCaps)
   if (!I.have_norms) {
     I.d_pnorm2.ensure((size_t)I.view.n);
     I.d_pnorm2_max.ensure(1);

@@ -20,6 +20,9 @@ typedef unsigned long long u64;
 #define WANN_PROF_PTR(p) ((unsigned long long *)nullptr)
 #endif
 
+#define WANN_LIKELY(x) __builtin_expect(!!(x), 1)
+#define WANN_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 #define WAVE_SYNC()                                            \
   do {                                                         \
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     \
@@ -1229,7 +1232,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     // ---- visit the closest unvisited entry of the beam (beamSearch.h:108-117): the closer of the first unvisited
     //      entry of the LDS beam and the first unvisited entry of the delta list
     if ((pmk == ~0ull && dhead == ~0ull) || nvis >= lim) break;
-    if (check_abort && (nvis & 31) == 0) {
+    if (WANN_UNLIKELY(check_abort && (nvis & 31) == 0)) {
       int ab = 0;
       if (lane == 0) ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (uni(ab) == 2) break;
@@ -1237,7 +1240,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     const bool from_delta = (dhead | 1ull) < (pmk | 1ull);
     int cur;
     bool consumed = false;  // the visited entry had a packet requested
-    if (from_delta) {
+    if (WANN_UNLIKELY(from_delta)) {
       cur = (int)((uint32_t)dhead >> 1);
       if (dk == dhead) dk |= 1ull;  // (keys are unique)
       const u64 du = ballot64(lane < D && !(dk & 1ull));
@@ -1263,7 +1266,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     float pk_dist = 0.f;
     u64 pk_mask = 0;
     bool valid;
-    if (cur == nx_node && !from_delta) {
+    if (WANN_LIKELY(cur == nx_node && !from_delta)) {
       st_nx += (lane == 0) ? 1 : 0;
       a = nx_a;
       loc = nx_loc;
@@ -1291,12 +1294,13 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
 
     // ---- the window follows the first unvisited entry; packets are requested for the next four unvisited entries
     if (!from_delta) {
-      if (popc64(wum) < 4 && wbase + 64 < M) load_window(wum ? wbase + ctz64(wum) : wbase + 64);
+      if (WANN_UNLIKELY(popc64(wum) < 4 && wbase + 64 < M)) load_window(wum ? wbase + ctz64(wum) : wbase + 64);
       else pmk = wum ? rdlane64(wv, ctz64(wum)) : ~0ull;
     }
     if (box) {
 #pragma unroll
       for (int r = 0; r < 2; r++) {  // (one per hop keeps the distance; two catch up after a restart)
+        if (r == 1 && WANN_LIKELY(nreq - rq_next >= 4)) break;
         u64 cand = wum;
         const int rel = req_pos - wbase;  // window bits <= rel have been requested
         if (rel >= 63) cand = 0;
@@ -1318,7 +1322,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     // ---- lossy seen-filter (sequential semantics, beamSearch.h:68-73,126-131) + exact seen set
     const int tagged = (int)(tag | (uint32_t)a);
     bool clash;
-    if (flags & 2) clash = (flags & 1) != 0;  // (the helper's exact test)
+    if (WANN_LIKELY(flags & 2)) clash = (flags & 1) != 0;  // (the helper's exact test)
     else {
       // exact test "two valid lanes of the row share a filter slot": every lane tags its slot of a small LDS hash with
       // its lane number; a lane that lost its slot compares filter slots with the winner, and the few lanes whose
@@ -1340,7 +1344,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     clash = uni((int)clash) != 0;
     WANN_PHASE(3);  // slot-sharing test
     bool seen, twice = false;
-    if (!clash) {
+    if (WANN_LIKELY(!clash)) {
       seen = valid && (old == tagged);
       if (valid) gtable[loc] = tagged;
     } else {  // exact emulation of the sequential rule (as in wave_beam_search)
@@ -1390,12 +1394,12 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     }
     WANN_PHASE(5);  // next hop's packet and probes
 
-    if (twice) flush();  // the exact multiset union below works on the whole beam
+    if (WANN_UNLIKELY(twice)) flush();  // the exact multiset union below works on the whole beam
     // ---- score (beamSearch.h:135-145).  Distances: from the packet where it holds them; what it lacks (no packet, or a
     //      neighbour the helper took for scored already) is computed here
     float dist = pk_dist;
     const bool need = take && !((pk_mask >> lane) & 1ull);
-    if (ballot64(need)) {
+    if (WANN_UNLIKELY(ballot64(need) != 0)) {
       st_own += (lane == 0) ? 1 : 0;
       // (the delta list waits in the merge scratch meanwhile: the scoring routine keeps a whole row per lane pair in
       // flight and needs every register)
@@ -1410,13 +1414,13 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     WANN_PHASE(6);  // distances
 
     // ---- union + truncate (beamSearch.h:148-157)
-    if (twice) {
+    if (WANN_UNLIKELY(twice)) {
       int p0;
       const int pm = wum ? wbase + ctz64(wum) : M;
       M = wave_merge(mb, M, B, pass, key, L.cand_key, &p0);
       resync(pm < p0 ? pm : p0);
     } else if (pmask) {
-      if (D + popc64(pmask) > 64) flush();
+      if (WANN_UNLIKELY(D + popc64(pmask) > 64)) flush();
       for (u64 mm = pmask; mm; mm &= mm - 1) {  // into the delta list: vector operations only after the broadcast
         const u64 k = rdlane64(key, ctz64(mm));
         const bool lt = (dk | 1ull) < (k | 1ull);  // (lanes >= D hold ~0: never)
@@ -1439,11 +1443,11 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
         } else {
           M--;
           if (M == 0) mlk = 0;
-          else if (M - 1 >= tb) mlk = rdlane64(tv, M - 1 - tb);
+          else if (WANN_LIKELY(M - 1 >= tb)) mlk = rdlane64(tv, M - 1 - tb);
           else load_tail();
         }
       }
-      if (M < wbase + 64) {  // the window lost entries
+      if (WANN_UNLIKELY(M < wbase + 64)) {  // the window lost entries
         const int keep = M - wbase;
         wum = keep <= 0 ? 0ull : (wum & ((((u64)1 << (keep - 1)) << 1) - 1));
         if (!wum) pmk = ~0ull;

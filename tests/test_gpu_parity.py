@@ -738,7 +738,9 @@ def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
 # dense prefilter path (queries sharing a window -> MFMA GEMM + exact re-rank), adversarial-style data
 # (generate_datasets/generate_advserial_dataset.py:8-69: clusters, labels c - 0.5 + U(0,1), one window per cluster)
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("metric,sfx,d", [("mips", "FloatMips", 100), ("l2", "FloatEuclidian", 128), ("l2f", "FloatEuclidian", 96)])
+@pytest.mark.parametrize("metric,sfx,d", [("mips", "FloatMips", 100), ("l2", "FloatEuclidian", 128), ("l2f", "FloatEuclidian", 96),
+                                          ("mips", "FloatMips", 512), ("mips", "FloatMips", 300), ("l2f", "FloatEuclidian", 200),
+                                          ("l2", "FloatEuclidian", 384)])  # (129 .. 512: the wide kernel, 2 / 3 / 4 slabs, partial last slab)
 def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sfx, d):
     rng = np.random.default_rng(17)
     nclu, per, qper = 12, 1500, 40
@@ -778,7 +780,7 @@ def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sf
 
 
 @pytest.mark.parametrize("sfx,d,style", [("FloatMips", 100, "unit"), ("FloatEuclidian", 128, "sift"), ("FloatEuclidian", 24, "unit"),
-                                         ("FloatMips", 7, "drift")])
+                                         ("FloatMips", 7, "drift"), ("FloatMips", 512, "unit"), ("FloatEuclidian", 260, "unit")])
 def test_dense_prefilter_slices_and_tiles(wa, gpu, monkeypatch, sfx, d, style):
     """Windows longer than one slice (2 048 positions), longer than eight (the slice grows), groups of more than 128 queries
     (several tiles), duplicates (equal scores), and labels that correlate with the geometry (the best candidates all sit at

@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 
 def make():
     rng = np.random.default_rng(0)
-    nclu, per, d = 100, 10000, 100
+    nclu, per, d = 100, 10000, int(os.environ.get("WANN_PF_DIM", "100"))  # (WANN_PF_DIM=512: the RedCaps row length)
     n = nclu * per
     cent = rng.standard_normal((nclu, d)).astype(np.float32)
     X = cent[np.repeat(np.arange(nclu), per)] + 0.1 * rng.standard_normal((n, d)).astype(np.float32)
@@ -101,7 +101,7 @@ for th in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), max(1, ncpu // 8)}
 flops = 2.0 * nq * per * d
 scan_bytes = float(out["p12"]["counters"]["brute_rows"]) * d * 4  # w * d * sizeof(T) per brute-force query
 p12_dev_ms = out["p12"]["counters"]["device_ms"]
-print(json.dumps(dict(workload="adversarial 100x10000 d=100 MIPS, 9900 queries, window = 1 cluster", mfma_ms=out["mfma"]["ms"], mfma_qps=out["mfma"]["qps"],
+print(json.dumps(dict(workload=f"adversarial 100x10000 d={d} MIPS, 9900 queries, window = 1 cluster", mfma_ms=out["mfma"]["ms"], mfma_qps=out["mfma"]["qps"],
                       scan_ms=out["scan"]["ms"], scan_qps=out["scan"]["qps"], mfma_equals_scan=bool(same),
                       gemm_queries=out["mfma"]["counters"]["gemm_queries"], gemm_unproven=out["mfma"]["counters"]["gemm_unproven"], gemm_rescued=out["mfma"]["counters"]["gemm_rescued"], device_ms=round(out["mfma"]["counters"]["device_ms"], 3), gemm_tflops_incl_select=round(flops / out["mfma"]["ms"] / 1e9, 2),
                       cpu_reference=cpu.get("native"),

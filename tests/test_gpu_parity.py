@@ -54,11 +54,14 @@ def _hash64_2(x):
 
 
 @pytest.mark.parametrize("env", [{}, {"WANN_FORCE_GENERAL": "1"}, {"WANN_OLD_GENERAL": "1"}, {"WANN_RAW_BIG_LDS": "1"},
-                                 {"WANN_RAW_BIG_LDS": "1", "WANN_FORCE_GENERAL": "1"}], ids=lambda e: "+".join(sorted(e)) or "default")
+                                 {"WANN_RAW_BIG_LDS": "1", "WANN_FORCE_GENERAL": "1"},
+                                 {"WANN_RAW_BIG_LDS": "1", "WANN_FORCE_GENERAL": "1", "WANN_NO_HELPER": "1"}],  # (the search wave without its helper waves)
+                         ids=lambda e: "+".join(sorted(e)) or "default")
 @pytest.mark.parametrize("metric,gen,d", [(0, sift_like, 128), (1, unit_mixture, 100)])
 def test_raw_beam_search_core_variants(oracle, wa, gpu, monkeypatch, env, metric, gen, d):
     """Every beam-search core (register-resident, second-generation general with the exact seen set / delta list / tagged
-    filter, first-generation general, one- and four-wave kernels) against the oracle: ids, distances, hops, dist_cmps.
+    filter -- fed by its scoring helper waves and without them --, first-generation general, one- and four-wave kernels)
+    against the oracle: ids, distances, hops, dist_cmps.
     The graph has rows that list the start node twice with a node of the same filter slot in between -- the one case in
     which the reference's multiset union keeps two copies of an entry."""
     n, nq, R, L = 6000, 64, 32, 64

@@ -114,6 +114,9 @@ struct RouteArgs {
   int32_t big_cap;      // 0 = no such levels
   int32_t *big_list, *big_count;  // two classes, longest searches first: beams >= 4096 in big_list[0..), the
   int32_t big_stride;             // others in big_list[big_stride..); big_count[2]
+  // the speculating tasks with levels in big_list, one entry (the parent's task slot) each: what the idle pollers of
+  // k_search scan for chains that will outgrow their levels (may be null)
+  int32_t *scan_list, *scan_count;
   Counters *ctr;
 };
 
@@ -204,8 +207,8 @@ struct SearchArgs {
   int32_t *la_count;
   int32_t la_base0, la_cap, la_min_beam;
   int32_t scan_num;  // the scan asks for a look-ahead when the highest level is expected to find at most k * scan_num / 8 entries
-  int32_t scan_tasks, scan_min_top;  // idle pollers scan task slots [0, scan_tasks) for speculating tasks that will need the
-                                     // level after their highest one (highest beam >= scan_min_top); 0 = no scan
+  const int32_t *scan_list, *scan_count;  // idle pollers scan these speculating tasks (k_route's list) for ones that will
+  int32_t scan_min_top;                   // need the level after their highest one (highest beam >= scan_min_top); null = no scan
   int32_t la_found_max;  // a chain asks for a look-ahead when its last level found fewer in-window entries than this (0.4 k)
 };
 

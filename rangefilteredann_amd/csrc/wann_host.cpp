@@ -62,7 +62,7 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 }
 
 constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_POLL_WAITING = 146, I_PRIO_COUNT = 147, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
+enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_POLL_WAITING = 146, I_PRIO_COUNT = 147, I_SCAN_COUNT = 148, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
 
 struct Workspace {
@@ -105,7 +105,7 @@ struct Workspace {
     list_final.ensure(nt);
     list_heavy.ensure(nt);
     list_mid.ensure(nt);
-    list_big.ensure(3 * nt);
+    list_big.ensure(4 * nt);
     next_beam.ensure(nt);
     big_stride = (int32_t)nt;
     list_brute.ensure(nt);
@@ -547,6 +547,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.big_list = W.list_big.p;
   ra.big_count = W.ints.p + I_BIG_COUNT;
   ra.big_stride = W.big_stride;
+  ra.scan_list = W.list_big.p + 3 * (size_t)W.big_stride;
+  ra.scan_count = W.ints.p + I_SCAN_COUNT;
   ra.ctr = W.ctr.p;
   if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
   // the list sizes come back while the exact scans run: the beam-search launches are sized by them, and skipped
@@ -706,7 +708,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
             a.la_min_beam = big.la_min_beam = (int32_t)std::max<int64_t>(4 * first_beam, 160);
             a.la_found_max = big.la_found_max = (int32_t)((2 * qp.k + 4) / 5);
             if (deep_pollers == 0 && scan_on) {  // (companion mode: there are speculating tasks)
-              big.scan_tasks = (int32_t)std::min<int64_t>(nq * maxt, INT32_MAX);
+              big.scan_list = W.list_big.p + 3 * (size_t)W.big_stride;
+              big.scan_count = W.ints.p + I_SCAN_COUNT;
               big.scan_min_top = getenv("WANN_SCAN_MIN_TOP") ? atoi(getenv("WANN_SCAN_MIN_TOP")) : 2560;
               big.scan_num = getenv("WANN_SCAN_NUM") ? atoi(getenv("WANN_SCAN_NUM")) : 16;
             }

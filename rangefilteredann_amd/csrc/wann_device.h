@@ -129,7 +129,8 @@ struct SearchArgs {
   const int32_t *list_count;
   const int32_t *heavy_list;   // served before `list` (may be null)
   const int32_t *heavy_count;
-  const int32_t *prio_count;   // entries stored from the end of heavy_list downwards, served first of all (may be null)
+  const int32_t *prio_list;    // prio_count entries stored from prio_list[heavy_cap - 1] downwards, served first of all
+  const int32_t *prio_count;   // (may be null)
   int32_t heavy_cap;
   const int32_t *mid_list;     // served between the two (may be null): a late doubling would be the tail of the launch
   const int32_t *mid_count;
@@ -212,6 +213,13 @@ struct SearchArgs {
   int32_t la_found_max;  // a chain asks for a look-ahead when its last level found fewer in-window entries than this (0.4 k)
 };
 
+struct OrderArgs {  // k_order_heavy: `in` (count entries: task slots) reordered into `out`
+  const Task *tasks;
+  const int32_t *in;
+  int32_t *out;
+  const int32_t *count;
+};
+
 struct BruteArgs {
   IndexView ix;
   const float *queries;
@@ -252,6 +260,7 @@ struct LaunchCfg {
   int big;              // the companion kernel for levels beyond cap_inkernel (k_search<METRIC, true>)
 };
 int launch_route(const RouteArgs &a, void *stream);
+int launch_order_heavy(const OrderArgs &a, void *stream);
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);
 int launch_brute(const BruteArgs &a, int blocks, void *stream);
 int launch_finalize(const FinalizeArgs &a, void *stream);

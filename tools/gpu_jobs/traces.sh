@@ -2,11 +2,9 @@
 O=gpurun_out/traces
 mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/tools/_scratch/trace:$LD_LIBRARY_PATH
-for run in 1 2 3 4 5; do
-for p in -11; do
-  WANN_TASK_TRACE=$O/trace$p.txt python tools/frac_probe.py --fractions=$p --settings 80,1 --reps 1 > $O/probe$p.$run.log 2>&1
-  python tools/trace_summary.py $O/trace$p.txt > $O/summary$p.$run.txt 2>&1
-  python tools/chain_evidence.py $O/trace$p.txt 10 > $O/chains$p.$run.txt 2>&1
+for p in -9 -8 -10; do
+  WANN_TASK_TRACE=$O/trace$p.txt python tools/frac_probe.py --fractions=$p --settings 80,1 --reps 1 > $O/probe$p.log 2>&1
+  python tools/trace_summary.py $O/trace$p.txt > $O/summary$p.txt 2>&1
+  python tools/chain_evidence.py $O/trace$p.txt 10 > $O/chains$p.txt 2>&1
   rm -f $O/trace$p.txt
-done
 done

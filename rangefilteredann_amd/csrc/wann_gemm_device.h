@@ -38,6 +38,7 @@ struct GemmArgs {
   int32_t *plan;             // P_*
   unsigned long long *score_used;  // floats of `scores` handed out so far
   GemmGroup *groups;
+  int32_t *tile_group;  // per tile: its group (score_cap / 1024 + 1 entries: the smallest group takes 1024 floats of scores per tile)
   int32_t *gq;        // grouped query rows
   int32_t *tq_group;  // per grouped query: its group and its row inside the group
   int32_t *tq_local;

@@ -98,63 +98,96 @@ __global__ void k_group_insert(GemmArgs A) {
   A.q_rank[q] = atomicAdd(&A.slot_count[pos], 1);
 }
 
+// exclusive prefix of v over the 1024 threads of the workgroup (+ the total): shuffles inside a wave, one pass over the 16
+// wave totals.  `wsum` is 16 entries of LDS; two barriers.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *wsum, T &total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  T inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const T u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
+  }
+  __syncthreads();  // (wsum may still be read from the previous scan)
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  T off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const T w = wsum[i];
+    off += (i < wv) ? w : (T)0;
+    tot += w;
+  }
+  total = tot;
+  return off + inc - v;
+}
+
 // one workgroup: every occupied slot becomes a group (or is left to the exact scan), with its share of the query
-// list, of the score buffer and of the tile numbers
+// list, of the score buffer and of the tile numbers -- prefix sums over the slots, 1024 at a time (a hundred threads adding to
+// the same three counters cost 20 us of serialised atomics)
 __global__ __launch_bounds__(1024) void k_group_plan(GemmArgs A, Counters *ctr) {
-  __shared__ int part[1024];
+  __shared__ unsigned long long wsum64[16];
+  __shared__ int wsum32[16];
   const int tid = threadIdx.x;
   if (tid == 0) *A.brute_count = 0;  // k_group_scatter rebuilds the exact-scan list
   const int nslots = A.plan[P_NSLOTS];
-  for (int i = tid; i < nslots; i += blockDim.x) {
-    const int pos = A.slot_list[i];
-    const unsigned long long key = A.slot_key[pos];
-    const int qc = A.slot_count[pos];
-    const int64_t a = (int64_t)(key >> 32), b = (int64_t)(key & 0xffffffffull), w = b - a;
-    int g = -1;
-    if (qc >= kGroupMinQueries && w >= kGroupMinWindow) {
-      // entries: per query and 128-position step two blocks (one per half wave) of four floats
-      const unsigned long long need = (unsigned long long)qc * (unsigned long long)((w + 127) >> 7) * 8ull;
-      const unsigned long long soff = atomicAdd(A.score_used, need);
-      if (soff + need <= (unsigned long long)A.score_cap) {
-        g = atomicAdd(&A.plan[P_NGROUPS], 1);
-        GemmGroup G;
-        G.a = a;
-        G.b = b;
-        G.soff = (int64_t)soff;
-        G.qoff = atomicAdd(&A.plan[P_NTQ], qc);
-        G.qcount = qc;
-        G.nqt = (qc + 127) >> 7;
-        G.nch = (int32_t)((w + kGemmPointChunk - 1) / kGemmPointChunk);
-        G.tile0 = 0;
-        G.pad = 0;
-        A.groups[g] = G;
-      }
+  unsigned long long used = 0;
+  int ngroups = 0, ntq = 0, ntiles = 0;
+  for (int i0 = 0; i0 < nslots; i0 += blockDim.x) {
+    const int i = i0 + tid;
+    int pos = 0, qc = 0;
+    int64_t a = 0, b = 0, w = 0;
+    bool eligible = false;
+    if (i < nslots) {
+      pos = A.slot_list[i];
+      const unsigned long long key = A.slot_key[pos];
+      qc = A.slot_count[pos];
+      a = (int64_t)(key >> 32);
+      b = (int64_t)(key & 0xffffffffull);
+      w = b - a;
+      eligible = qc >= kGroupMinQueries && w >= kGroupMinWindow;
     }
-    A.slot_group[pos] = g;
+    if (!__syncthreads_or(eligible)) {  // (a batch of distinct windows: thousands of slots, no group)
+      if (i < nslots) A.slot_group[pos] = -1;
+      continue;
+    }
+    // entries: per query and 128-position step two blocks (one per half wave) of four floats
+    const unsigned long long need = eligible ? (unsigned long long)qc * (unsigned long long)((w + 127) >> 7) * 8ull : 0ull;
+    unsigned long long need_total;
+    const unsigned long long soff = used + block_excl_scan(need, wsum64, need_total);
+    const bool fits = eligible && soff + need <= (unsigned long long)A.score_cap;
+    const int nqt = (qc + 127) >> 7, nch = (int)((w + kGemmPointChunk - 1) / kGemmPointChunk);
+    int g_total, q_total, t_total;
+    const int g = ngroups + block_excl_scan(fits ? 1 : 0, wsum32, g_total);
+    const int qoff = ntq + block_excl_scan(fits ? qc : 0, wsum32, q_total);
+    const int tile0 = ntiles + block_excl_scan(fits ? nqt * nch : 0, wsum32, t_total);
+    if (fits) {
+      GemmGroup G;
+      G.a = a;
+      G.b = b;
+      G.soff = (int64_t)soff;
+      G.qoff = qoff;
+      G.qcount = qc;
+      G.nqt = nqt;
+      G.nch = nch;
+      G.tile0 = tile0;
+      G.pad = 0;
+      A.groups[g] = G;
+      for (int t = 0; t < nqt * nch; t++) A.tile_group[tile0 + t] = g;
+    }
+    if (i < nslots) A.slot_group[pos] = fits ? g : -1;
+    used += need_total;
+    ngroups += g_total;
+    ntq += q_total;
+    ntiles += t_total;
   }
-  __syncthreads();
-  // tile numbers: an exclusive scan of nqt * nch over the groups (each thread takes a run of groups)
-  const int ng = A.plan[P_NGROUPS];
-  const int per = (ng + blockDim.x - 1) / blockDim.x;
-  const int g0 = min(tid * per, ng), g1 = min(g0 + per, ng);
-  int sum = 0;
-  for (int g = g0; g < g1; g++) sum += A.groups[g].nqt * A.groups[g].nch;
-  part[tid] = sum;
-  __syncthreads();
-  for (int o = 1; o < (int)blockDim.x; o <<= 1) {
-    const int v = (tid >= o) ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = part[tid] - sum;
-  for (int g = g0; g < g1; g++) {
-    A.groups[g].tile0 = run;
-    run += A.groups[g].nqt * A.groups[g].nch;
-  }
-  if (tid == (int)blockDim.x - 1) {
-    A.plan[P_NTILES] = part[tid];
-    ctr->gemm_queries = (unsigned long long)A.plan[P_NTQ];
+  if (tid == 0) {
+    A.plan[P_NGROUPS] = ngroups;
+    A.plan[P_NTQ] = ntq;
+    A.plan[P_NTILES] = ntiles;
+    *A.score_used = used;
+    ctr->gemm_queries = (unsigned long long)ntq;
   }
 }
 
@@ -188,6 +221,29 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t 
   lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
+// x into the sorted m1 <= m2 <= m3 <= m4 (the largest drops out): m_i' = x clamped to [m_(i-1), m_i], four independent
+// instructions.  (Written as instructions: through the builtins the compiler first canonicalises x -- it is made of integer
+// operations, a signalling NaN for all it knows -- with a fifth one; the scores are finite.)
+__device__ __forceinline__ void insert4(float &m1, float &m2, float &m3, float &m4, float x) {
+  asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(m4) : "v"(m3), "v"(x));
+  asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(m3) : "v"(m2), "v"(x));
+  asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(m2) : "v"(m1), "v"(x));
+  asm volatile("v_min_f32 %0, %0, %1" : "+v"(m1) : "v"(x));
+}
+
+__device__ __forceinline__ void insert4_chain(float &m1, float &m2, float &m3, float &m4, float x) {  // the same, seven dependent ones
+  float a = fminf(m1, x);
+  x = fmaxf(m1, x);
+  m1 = a;
+  a = fminf(m2, x);
+  x = fmaxf(m2, x);
+  m2 = a;
+  a = fminf(m3, x);
+  x = fmaxf(m3, x);
+  m3 = a;
+  m4 = fminf(m4, x);
+}
+
 // One workgroup (4 waves, one per SIMD) per tile = (group, 128 queries, one slice of the window); tiles are taken
 // round-robin by a grid of one workgroup per CU.  Per step the workgroup stages 128 points in the LDS as [hi | lo] bf16
 // rows; every wave owns 32 query rows (A operand: bf16 pairs in registers for the whole tile) and scores them against
@@ -208,20 +264,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_scores(GemmArgs A) {
   const int half = lane >> 5, col = lane & 31;
   const bool mips = ix.metric == 1;
   const float scale = mips ? -1.f : -2.f;
-  const int ntiles = A.plan[P_NTILES], ng = A.plan[P_NGROUPS];
+  const int ntiles = A.plan[P_NTILES];
 #ifdef WANN_GEMM_PROF
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long tk0 = __builtin_readcyclecounter();
 #endif
 
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    int glo = 0, ghi = ng - 1;  // the last group whose first tile is <= t
-    while (glo < ghi) {
-      const int mid = (glo + ghi + 1) >> 1;
-      if (A.groups[mid].tile0 <= t) glo = mid;
-      else ghi = mid - 1;
-    }
-    const GemmGroup grp = A.groups[glo];
+    const GemmGroup grp = A.groups[A.tile_group[t]];
     const int tl = t - grp.tile0, ch = tl / grp.nqt, q0 = (tl - ch * grp.nqt) << 7;
     const int64_t w = grp.b - grp.a, wlast = w - 1;
     const int64_t p_begin = (int64_t)ch * kGemmPointChunk;
@@ -345,17 +395,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_scores(GemmArgs A) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float sc = fmaf(scale, acc[j][4 * g + r], b4[r]);
-            float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
-            float a = fminf(m1, x);
-            x = fmaxf(m1, x);
-            m1 = a;
-            a = fminf(m2, x);
-            x = fmaxf(m2, x);
-            m2 = a;
-            a = fminf(m3, x);
-            x = fmaxf(m3, x);
-            m3 = a;
-            m4 = fminf(m4, x);
+            const float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
+            if constexpr (STRIDE < 128) insert4(m1, m2, m3, m4, x);
+            else insert4_chain(m1, m2, m3, m4, x);  // (at 128 floats per row the four-instruction form does not fit 256 registers)
           }
         }
       if (live) erow[(c0 - p_begin) >> 6] = f32x4{m1, m2, m3, m4};
@@ -398,17 +440,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
   const int half = lane >> 5, col = lane & 31;
   const bool mips = ix.metric == 1;
   const float scale = mips ? -1.f : -2.f;
-  const int ntiles = A.plan[P_NTILES], ng = A.plan[P_NGROUPS];
+  const int ntiles = A.plan[P_NTILES];
   const int stride = ix.stride;
 
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    int glo = 0, ghi = ng - 1;  // the last group whose first tile is <= t
-    while (glo < ghi) {
-      const int mid = (glo + ghi + 1) >> 1;
-      if (A.groups[mid].tile0 <= t) glo = mid;
-      else ghi = mid - 1;
-    }
-    const GemmGroup grp = A.groups[glo];
+    const GemmGroup grp = A.groups[A.tile_group[t]];
     const int tl = t - grp.tile0, ch = tl / grp.nqt, q0 = (tl - ch * grp.nqt) << 7;
     const int64_t w = grp.b - grp.a, wlast = w - 1;
     const int64_t p_begin = (int64_t)ch * kGemmPointChunk;
@@ -558,17 +594,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float sc = fmaf(scale, acc[j][4 * g + r], b4[r]);
-            float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
-            float a = fminf(m1, x);
-            x = fmaxf(m1, x);
-            m1 = a;
-            a = fminf(m2, x);
-            x = fmaxf(m2, x);
-            m2 = a;
-            a = fminf(m3, x);
-            x = fmaxf(m3, x);
-            m3 = a;
-            m4 = fminf(m4, x);
+            const float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
+            insert4(m1, m2, m3, m4, x);
           }
         }
       if (live) erow[(c0 - p_begin) >> 6] = f32x4{m1, m2, m3, m4};

@@ -154,7 +154,7 @@ struct wann_index {
   DevBuf<unsigned int> d_pnorm2_max;
   bool have_norms = false;
   DevBuf<GemmGroup> g_groups;
-  DevBuf<int32_t> g_gq, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan, g_sel_pos, g_sel_cnt;
+  DevBuf<int32_t> g_gq, g_tile_group, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan, g_sel_pos, g_sel_cnt;
   DevBuf<unsigned long long> g_slot_key, g_score_used;
   DevBuf<float> g_scores, g_sel_cut, g_sel_bound;
   DevBuf<unsigned long long> g_prof;
@@ -426,6 +426,7 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   // (a window group uses queries x its own blocks x 8 floats: 25 MB for the adversarial batch; what does not fit the cap takes the exact scan)
   const size_t score_cap = (size_t)std::min<unsigned long long>((unsigned long long)nq * (unsigned long long)((I.view.n + 127) / 128) * 8ull, 64ull << 20);
   I.g_scores.ensure(score_cap);
+  I.g_tile_group.ensure(score_cap / 1024 + 1);
   GemmArgs ga{};
   ga.ix = I.view;
   ga.queries = d_queries;
@@ -441,6 +442,7 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   ga.plan = I.g_plan.p;
   ga.score_used = I.g_score_used.p;
   ga.groups = I.g_groups.p;
+  ga.tile_group = I.g_tile_group.p;
   ga.gq = I.g_gq.p;
   ga.tq_group = I.g_tq_group.p;
   ga.tq_local = I.g_tq_local.p;

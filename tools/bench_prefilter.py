@@ -88,7 +88,7 @@ res_path = "/tmp/wann_prefilter_gpu_rows.npz"
 np.savez(res_path, d_native=out["mfma"]["d"], d_p12=out["p12"]["d"])
 cpu = {}
 ncpu = os.cpu_count() or 1
-for th in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), max(1, ncpu // 8)}, reverse=True):
+for th in ([] if os.environ.get("WANN_PF_NO_REF") else sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), max(1, ncpu // 8)}, reverse=True)):  # (WANN_PF_NO_REF=1: dev runs)
     try:
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--ref-worker", res_path], env=dict(os.environ, PARLAY_NUM_THREADS=str(th)),
                            capture_output=True, text=True, timeout=900)

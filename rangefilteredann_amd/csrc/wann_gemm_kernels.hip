@@ -134,6 +134,19 @@ __global__ __launch_bounds__(1024) void k_group_plan(GemmArgs A, Counters *ctr) 
   const int nslots = A.plan[P_NSLOTS];
   unsigned long long used = 0;
   int ngroups = 0, ntq = 0, ntiles = 0;
+  // (a batch of distinct windows -- thousands of slots, no group -- is settled in one pass of independent loads)
+  bool any = false;
+#pragma unroll 4
+  for (int i = tid; i < nslots; i += blockDim.x) {
+    const int pos = A.slot_list[i];
+    const unsigned long long key = A.slot_key[pos];
+    any |= A.slot_count[pos] >= kGroupMinQueries && (int64_t)(key & 0xffffffffull) - (int64_t)(key >> 32) >= kGroupMinWindow;
+  }
+  if (!__syncthreads_or(any)) {
+    for (int i = tid; i < nslots; i += blockDim.x) A.slot_group[A.slot_list[i]] = -1;
+    if (tid == 0) ctr->gemm_queries = 0;
+    return;  // (the plan's counts are zero already: k_group_clear)
+  }
   for (int i0 = 0; i0 < nslots; i0 += blockDim.x) {
     const int i = i0 + tid;
     int pos = 0, qc = 0;

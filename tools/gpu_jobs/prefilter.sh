@@ -2,6 +2,6 @@
 O=gpurun_out/prefilter
 mkdir -p $O
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "prefilter or dense or gemm" > $O/tests.log 2>&1
-LD_LIBRARY_PATH=$PWD/tools/_scratch/prof:$LD_LIBRARY_PATH WANN_PF_NO_REF=1 python tools/bench_prefilter.py > $O/prof.json 2> $O/prof.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 WANN_PF_NO_REF=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 tools/bench_prefilter.py > $O/bench.json 2> $O/bench.err
+WANN_PF_NO_REF=1 WANN_PF_DIM=32 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof32 -- python3 tools/bench_prefilter.py > $O/bench32.json 2> $O/bench32.err

@@ -487,7 +487,7 @@ def _continuation_case(wa):
     return idx, Q, labels, nq
 
 
-@pytest.mark.parametrize("variant", ["default", "WANN_SCAN=0", "WANN_LA_EAGER"])
+@pytest.mark.parametrize("variant", ["default", "WANN_SCAN=0", "WANN_LA_EAGER", "WANN_NO_ORDER"])
 def test_mid_fraction_machinery_matches_oracle(oracle, wa, gpu, tmp_path, monkeypatch, variant):
     """The scheduling machinery of the mid window fractions -- speculative levels, the companion launch of the one-wave kernel
     (search wave + scoring helper waves), pollers, look-aheads, deep hand-offs -- against the ORACLE (not against itself) at
@@ -502,6 +502,8 @@ def test_mid_fraction_machinery_matches_oracle(oracle, wa, gpu, tmp_path, monkey
         monkeypatch.setenv("WANN_SCAN", "0")
     if variant == "WANN_LA_EAGER":  # (every chain that fails its second level asks for a look-ahead)
         monkeypatch.setenv("WANN_LA_EAGER", "1")
+    if variant == "WANN_NO_ORDER":  # (the heavy list in query order instead of longest first: k_order_heavy off)
+        monkeypatch.setenv("WANN_NO_ORDER", "1")
     monkeypatch.setenv("WANN_DEEP_MIN_TASKS", "1")  # (800 tasks would not count as a saturated launch)
     idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, cache))
     ref = oracle.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=oracle.BuildParams(24, 64, 1.0, cache))

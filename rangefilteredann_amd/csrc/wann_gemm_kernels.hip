@@ -136,7 +136,6 @@ __global__ __launch_bounds__(1024) void k_group_plan(GemmArgs A, Counters *ctr) 
   int ngroups = 0, ntq = 0, ntiles = 0;
   // (a batch of distinct windows -- thousands of slots, no group -- is settled in one pass of independent loads)
   bool any = false;
-#pragma unroll 4
   for (int i = tid; i < nslots; i += blockDim.x) {
     const int pos = A.slot_list[i];
     const unsigned long long key = A.slot_key[pos];
@@ -160,10 +159,6 @@ __global__ __launch_bounds__(1024) void k_group_plan(GemmArgs A, Counters *ctr) 
       b = (int64_t)(key & 0xffffffffull);
       w = b - a;
       eligible = qc >= kGroupMinQueries && w >= kGroupMinWindow;
-    }
-    if (!__syncthreads_or(eligible)) {  // (a batch of distinct windows: thousands of slots, no group)
-      if (i < nslots) A.slot_group[pos] = -1;
-      continue;
     }
     // entries: per query and 128-position step two blocks (one per half wave) of four floats
     const unsigned long long need = eligible ? (unsigned long long)qc * (unsigned long long)((w + 127) >> 7) * 8ull : 0ull;

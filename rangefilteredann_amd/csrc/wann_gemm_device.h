@@ -44,12 +44,8 @@ struct GemmArgs {
   int32_t *tq_local;
   const float *pnorm2;
   const unsigned int *pnorm2_max_bits;
-  float *scores;      // what k_gemm_scores hands to k_select_scores: per query, step and half wave the four smallest scores
+  float *scores;      // what k_gemm_scores hands to k_rerank's selection: per query, step and half wave the four smallest scores
   int64_t score_cap;  // floats; groups that do not fit any more are left to the exact scan
-  int32_t *sel_pos;   // [ntq][kSelect] window-relative positions
-  int32_t *sel_cnt;
-  float *sel_cut;     // the worst selected candidate's score once kSelect are selected (FLT_MAX before that): what lost against them
-  float *sel_bound;   // the smallest fourth entry of the window's blocks (FLT_MAX: no block kept anything back)
   int32_t k;
   unsigned long long *out_key;
   int32_t *out_cnt;

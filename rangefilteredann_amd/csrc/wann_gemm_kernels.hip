@@ -13,7 +13,7 @@
 //                    The scores never reach memory: every lane owns 64 of them per step (one query, 64 window
 //                    positions) and keeps their four smallest in registers (min / max insertion, no branches; the
 //                    position travels in the six low mantissa bits); one 16-byte store per lane and step leaves
-//   k_select_scores  per query: the 32 best of its blocks' (three smallest) entries; the fourth smallest of every block
+//   select_scores    (first half of k_rerank) per query: the 32 best of its blocks' (three smallest) entries; the fourth smallest of every block
 //                    bounds what the block did not hand over
 //   k_rerank         per query: exact reference-order distances of those 32 candidates, ordered by
 //                    (dist, id), first k; plus a proof that no unselected point can belong to the
@@ -617,13 +617,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
 // the low mantissa bits).  The first three of every block are candidates, the fourth bounds everything the block kept
 // to itself.  The kSelect best candidates live sorted in lanes 0 .. kSelect-1 (score bits in one register, window
 // positions in another); candidates below the current cut are inserted one by one with a ballot + one-lane shift.
-__global__ __launch_bounds__(256) void k_select_scores(GemmArgs A) {
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
-  const int64_t ntq = A.plan[P_NTQ];
-  for (int64_t tq = (int64_t)blockIdx.x * 4 + wv; tq < ntq; tq += (int64_t)gridDim.x * 4) {
-    const GemmGroup grp = A.groups[A.tq_group[tq]];
-    const int64_t w = grp.b - grp.a, nblk = ((w + 127) >> 7) * 2;
-    const f32x4 *erow = reinterpret_cast<const f32x4 *>(A.scores + grp.soff) + (int64_t)A.tq_local[tq] * nblk;
+// (one wave, one query; result in registers: lane l < filled holds the window-relative position of a selected candidate,
+// `cut` / `blk_bound` are the two bounds on everything that was not selected, FLT_MAX = nothing was left out that way)
+__device__ __forceinline__ void select_scores(const f32x4 *erow, int64_t nblk, int &sel_pos, int &sel_cnt, float &cut, float &blk_bound) {
+  const int lane = lane_id();
+  {
     uint32_t top_s = 0xffffffffu, thr = 0xffffffffu;  // 0xffffffff (no float maps to it) = empty slot; thr = lane kSelect-1
     int top_p = 0, filled = 0;
     float bound = kHuge;
@@ -683,16 +681,15 @@ __global__ __launch_bounds__(256) void k_select_scores(GemmArgs A) {
       }
     }
     for (int o = 32; o > 0; o >>= 1) bound = fminf(bound, __shfl_xor(bound, o));
-    if (lane < filled) A.sel_pos[tq * kSelect + lane] = top_p;
-    if (lane == 0) {
-      // every position that is not selected scores >= cut: candidates that were dropped or never inserted >= the worst
-      // selected one (once the list is full), everything else >= its block's fourth smallest
-      A.sel_cnt[tq] = filled;
-      A.sel_cut[tq] = (filled == kSelect) ? funkey(thr) : 3.402823466e+38f;
-      A.sel_bound[tq] = (bound >= kHugeTest) ? 3.402823466e+38f : bound;
-    }
+    // every position that is not selected scores >= cut: candidates that were dropped or never inserted >= the worst
+    // selected one (once the list is full), everything else >= its block's fourth smallest
+    sel_pos = top_p;
+    sel_cnt = filled;
+    cut = (filled == kSelect) ? funkey(thr) : 3.402823466e+38f;
+    blk_bound = (bound >= kHugeTest) ? 3.402823466e+38f : bound;
   }
 }
+
 
 // one wave per grouped query: exact distances of the selected candidates, (dist, id) order, proof
 template <int METRIC>
@@ -707,16 +704,19 @@ __global__ __launch_bounds__(256) void k_rerank(GemmArgs A, Counters *ctr) {
   for (int64_t tq = (int64_t)blockIdx.x * 4 + wv; tq < ntq; tq += (int64_t)gridDim.x * 4) {
     const GemmGroup grp = A.groups[A.tq_group[tq]];
     const int qrow = A.gq[tq];
-    const int cnt = A.sel_cnt[tq];
-    float q2 = 0.f;
+    float q2 = 0.f;  // (the query row is on its way while the selection runs)
     for (int i = lane; i < ix.stride; i += 64) {
       const float v = (i < ix.d) ? A.queries[(int64_t)qrow * ix.d + i] : 0.f;
       L.qv[i] = v;
       q2 = fmaf(v, v, q2);
     }
+    const int64_t nblk_sel = ((grp.b - grp.a + 127) >> 7) * 2;
+    int sel_pos, cnt;
+    float cut_sel, cut_blk;
+    select_scores(reinterpret_cast<const f32x4 *>(A.scores + grp.soff) + (int64_t)A.tq_local[tq] * nblk_sel, nblk_sel, sel_pos, cnt, cut_sel, cut_blk);
     for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
     int rid = 0;
-    if (lane < cnt) rid = ix.fi_sorted[grp.a + A.sel_pos[tq * kSelect + lane]];
+    if (lane < cnt) rid = ix.fi_sorted[grp.a + sel_pos];
     L.cand_id[lane] = rid;
     WAVE_SYNC();
     const float dist = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, cnt, 0);
@@ -745,7 +745,6 @@ __global__ __launch_bounds__(256) void k_rerank(GemmArgs A, Counters *ctr) {
     // two bounds on what was not selected: candidates that lost against the selected ones (>= the worst selected), and
     // whatever the blocks kept to themselves (>= the smallest fourth entry); FLT_MAX = no such position exists
     const float qoff = (METRIC == 1) ? 0.f : q2;  // the L2 scores leave |q|^2 out
-    const float cut_sel = A.sel_cut[tq], cut_blk = A.sel_bound[tq];
     const bool sel_ok = cut_sel == 3.402823466e+38f || (cnt >= K && dk + E < cut_sel + qoff - E);
     const bool blk_ok = cut_blk == 3.402823466e+38f || (cnt >= K && dk + E < cut_blk + qoff - E);
     bool proven = sel_ok && blk_ok;
@@ -868,8 +867,6 @@ int launch_gemm_scores(const GemmArgs &a, int num_cus, void *stream) {
 int launch_select_rerank(const GemmArgs &a, Counters *ctr, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const int blocks = (int)std::min<int64_t>(4096, (a.nq + 3) / 4);
-  hipLaunchKernelGGL(k_select_scores, dim3(blocks), dim3(256), 0, s, a);
-  if (gcheck(hipGetLastError())) return 1;
   const size_t lds = (size_t)4 * (((a.ix.stride * 4 + 15) & ~15) + 64 * 8 + 64 * 4 + 64 * 4 + ((a.k + 1) & ~1) * 8);
   if (a.ix.metric == 1) hipLaunchKernelGGL(k_rerank<1>, dim3(blocks), dim3(256), lds, s, a, ctr);
   else hipLaunchKernelGGL(k_rerank<0>, dim3(blocks), dim3(256), lds, s, a, ctr);

@@ -154,9 +154,9 @@ struct wann_index {
   DevBuf<unsigned int> d_pnorm2_max;
   bool have_norms = false;
   DevBuf<GemmGroup> g_groups;
-  DevBuf<int32_t> g_gq, g_tile_group, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan, g_sel_pos, g_sel_cnt;
+  DevBuf<int32_t> g_gq, g_tile_group, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan;
   DevBuf<unsigned long long> g_slot_key, g_score_used;
-  DevBuf<float> g_scores, g_sel_cut, g_sel_bound;
+  DevBuf<float> g_scores;
   DevBuf<unsigned long long> g_prof;
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
@@ -391,7 +391,7 @@ int method_code(const char *m) {
 // PrefilterIndex batches in which many queries share a window: those windows are scored as Q x P^T GEMMs on the
 // matrix cores (wann_gemm_kernels.hip), ~32 candidates per query are kept and re-ranked exactly; everything else (and
 // every query whose top-k cannot be proven from the MFMA scores) goes through the exact scan kernel.  Grouping,
-// tile planning and the hand-over to the exact scan all happen on the device: the host enqueues seven launches and
+// tile planning and the hand-over to the exact scan all happen on the device: the host enqueues six launches and
 // never waits.
 void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, hipStream_t st) {
   Workspace &W = I.ws;
@@ -417,10 +417,6 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   I.g_gq.ensure((size_t)nq);
   I.g_tq_group.ensure((size_t)nq);
   I.g_tq_local.ensure((size_t)nq);
-  I.g_sel_pos.ensure((size_t)nq * kSelect);
-  I.g_sel_cnt.ensure((size_t)nq);
-  I.g_sel_cut.ensure((size_t)nq);
-  I.g_sel_bound.ensure((size_t)nq);
   // the blocks' hand-over (two blocks of four floats per query and 128 window positions), capped at 256 MiB (groups
   // beyond that take the exact scan)
   // (a window group uses queries x its own blocks x 8 floats: 25 MB for the adversarial batch; what does not fit the cap takes the exact scan)
@@ -450,10 +446,6 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   ga.pnorm2_max_bits = I.d_pnorm2_max.p;
   ga.scores = I.g_scores.p;
   ga.score_cap = (int64_t)score_cap;
-  ga.sel_pos = I.g_sel_pos.p;
-  ga.sel_cnt = I.g_sel_cnt.p;
-  ga.sel_cut = I.g_sel_cut.p;
-  ga.sel_bound = I.g_sel_bound.p;
   ga.k = k;
   ga.out_key = W.out_key.p;
   ga.out_cnt = W.out_cnt.p;
@@ -466,7 +458,7 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
 #endif
   if (launch_group_windows(ga, W.ctr.p, st)) throw HipError(std::string("k_group_*: ") + gemm_launch_last_error());
   if (launch_gemm_scores(ga, I.num_cus, st)) throw HipError(std::string("k_gemm_scores: ") + gemm_launch_last_error());
-  if (launch_select_rerank(ga, W.ctr.p, st)) throw HipError(std::string("k_select_scores / k_rerank: ") + gemm_launch_last_error());
+  if (launch_select_rerank(ga, W.ctr.p, st)) throw HipError(std::string("k_rerank: ") + gemm_launch_last_error());
 #ifdef WANN_GEMM_PROF
   unsigned long long h[8];
   HIP_CHECK(hipMemcpyAsync(h, I.g_prof.p, 64, hipMemcpyDeviceToHost, st));

@@ -22,7 +22,7 @@ struct GemmGroup {   // queries sharing the window [a, b) of the label argsort
 };
 
 // device-side plan of one batch (k_group_*): counts written by the device, read by the kernels that follow
-enum { P_NGROUPS = 0, P_NTQ = 1, P_NTILES = 2, P_NSLOTS = 3, P_INTS = 4 };
+enum { P_NGROUPS = 0, P_NTQ = 1, P_NTILES = 2, P_NSLOTS = 3, P_ANY = 4 /* some slot has enough queries and a long enough window */, P_INTS = 5 };
 
 struct GemmArgs {
   IndexView ix;

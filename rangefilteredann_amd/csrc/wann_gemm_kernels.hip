@@ -73,6 +73,7 @@ __global__ void k_group_clear(GemmArgs A) {
   if (i <= A.cap_mask) {
     A.slot_key[i] = kEmptySlot;
     A.slot_count[i] = 0;
+    A.slot_group[i] = -1;  // (k_group_plan only writes the slots that become groups)
   }
   if (i < P_INTS) A.plan[i] = 0;
   if (i == 0) *A.score_used = 0;
@@ -88,14 +89,28 @@ __global__ void k_group_insert(GemmArgs A) {
   }
   const unsigned long long key = ((unsigned long long)(uint32_t)t.a << 32) | (uint32_t)t.b;
   uint32_t pos = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)A.cap_mask;
+  bool opened = false;
   for (;;) {
     const unsigned long long old = atomicCAS(&A.slot_key[pos], kEmptySlot, key);
-    if (old == kEmptySlot) A.slot_list[atomicAdd(&A.plan[P_NSLOTS], 1)] = (int32_t)pos;  // this thread opened the slot
+    opened = old == kEmptySlot;  // this thread opened the slot
     if (old == kEmptySlot || old == key) break;
     pos = (pos + 1) & (uint32_t)A.cap_mask;
   }
+  {  // the opened slots go on the list: one counter update per wave (a batch of distinct windows opens one per query)
+    const unsigned long long om = __ballot(opened);
+    if (om) {
+      const int lane = threadIdx.x & 63, leader = __builtin_ctzll(om);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&A.plan[P_NSLOTS], __builtin_popcountll(om));
+      base = __shfl(base, leader);
+      if (opened) A.slot_list[base + __builtin_popcountll(om & ((1ull << lane) - 1ull))] = (int32_t)pos;
+    }
+  }
   A.q_slot[q] = (int32_t)pos;
-  A.q_rank[q] = atomicAdd(&A.slot_count[pos], 1);
+  const int rank = atomicAdd(&A.slot_count[pos], 1);
+  A.q_rank[q] = rank;
+  // (the query that makes a slot a group says so: k_group_plan has nothing to do for a batch of distinct windows)
+  if (rank == kGroupMinQueries - 1 && t.b - t.a >= kGroupMinWindow) A.plan[P_ANY] = 1;
 }
 
 // exclusive prefix of v over the 1024 threads of the workgroup (+ the total): shuffles inside a wave, one pass over the 16
@@ -134,17 +149,10 @@ __global__ __launch_bounds__(1024) void k_group_plan(GemmArgs A, Counters *ctr) 
   const int nslots = A.plan[P_NSLOTS];
   unsigned long long used = 0;
   int ngroups = 0, ntq = 0, ntiles = 0;
-  // (a batch of distinct windows -- thousands of slots, no group -- is settled in one pass of independent loads)
-  bool any = false;
-  for (int i = tid; i < nslots; i += blockDim.x) {
-    const int pos = A.slot_list[i];
-    const unsigned long long key = A.slot_key[pos];
-    any |= A.slot_count[pos] >= kGroupMinQueries && (int64_t)(key & 0xffffffffull) - (int64_t)(key >> 32) >= kGroupMinWindow;
-  }
-  if (!__syncthreads_or(any)) {
-    for (int i = tid; i < nslots; i += blockDim.x) A.slot_group[A.slot_list[i]] = -1;
+  // (a batch of distinct windows -- thousands of slots, no group: k_group_insert would have said so)
+  if (A.plan[P_ANY] == 0) {
     if (tid == 0) ctr->gemm_queries = 0;
-    return;  // (the plan's counts are zero already: k_group_clear)
+    return;  // (the plan's counts are zero and every slot's group is -1 already: k_group_clear)
   }
   for (int i0 = 0; i0 < nslots; i0 += blockDim.x) {
     const int i = i0 + tid;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(1024) void k_group_plan(GemmArgs A, Counters *ctr) 
       A.groups[g] = G;
       for (int t = 0; t < nqt * nch; t++) A.tile_group[tile0 + t] = g;
     }
-    if (i < nslots) A.slot_group[pos] = fits ? g : -1;
+    if (fits) A.slot_group[pos] = g;
     used += need_total;
     ngroups += g_total;
     ntq += q_total;

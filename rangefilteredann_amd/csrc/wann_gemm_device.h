@@ -47,6 +47,7 @@ struct GemmArgs {
   float *scores;      // what k_gemm_scores hands to k_rerank's selection: per query, step and half wave the four smallest scores
   int64_t score_cap;  // floats; groups that do not fit any more are left to the exact scan
   int32_t k;
+  float acc_factor;  // safety factor on the fp32-accumulation term of the proof's error bound (k_rerank)
   unsigned long long *out_key;
   int32_t *out_cnt;
   int32_t *brute_list, *brute_count;  // exact scan: ungrouped queries + queries whose top-k could not be proven

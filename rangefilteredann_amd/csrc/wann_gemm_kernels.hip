@@ -738,9 +738,10 @@ __global__ __launch_bounds__(256) void k_rerank(GemmArgs A, Counters *ctr) {
     if (lane < cnt && rank < K) A.out_key[(size_t)ti * K + rank] = key;
     // proof: every unselected point has score >= cut, and |score - exact distance| <= E.
     // E: the products the bf16 split drops (q1 p3 + q3 p1 + q2 p2 + ...) <= 3.02 * 2^-16 |q||p| (Cauchy-Schwarz over
-    // the columns), fp32 accumulation of 3 d products (generous factor 8), fp32 norms and the reference's own rounding.
+    // the columns), fp32 accumulation of 3 d products (A.acc_factor x the rounding adder's worst case), fp32 norms and the
+    // reference's own rounding.
     const float pmax = __uint_as_float(*A.pnorm2_max_bits);
-    const float cerr = 3.02f * 1.52587890625e-5f + 8.f * (float)(3 * ix.d + 8) * 5.9604645e-8f;
+    const float cerr = 3.02f * 1.52587890625e-5f + A.acc_factor * (float)(3 * ix.d + 8) * 5.9604645e-8f;
     // + 2^-17 relative for the six mantissa bits that carry the position (|score| <= |q||p| resp. 2 (|q|^2 + |p|^2))
     const float cerr2 = cerr + 7.62939453125e-6f;
     const float E = (METRIC == 1) ? cerr2 * sqrtf(q2 * pmax) : 2.f * cerr2 * (q2 + pmax);

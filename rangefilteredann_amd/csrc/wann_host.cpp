@@ -447,6 +447,10 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   ga.scores = I.g_scores.p;
   ga.score_cap = (int64_t)score_cap;
   ga.k = k;
+  // fp32 accumulation of the 3 d exact bf16 x bf16 products of a score: worst case (3 d) u |q||p| for ANY order of the
+  // additions, u = 2^-24 with a rounding adder, 2^-23 with a truncating one; 3 = the truncating bound and half as much again.
+  // (Round 2 used 8: at d = 512 that one term was 7.4e-4 |q||p|, 46 % of the adversarial queries could not be proven.)
+  ga.acc_factor = getenv("WANN_PROOF_FACTOR") ? (float)atof(getenv("WANN_PROOF_FACTOR")) : 3.f;  // (dev knob)
   ga.out_key = W.out_key.p;
   ga.out_cnt = W.out_cnt.p;
   ga.brute_list = W.list_brute.p;

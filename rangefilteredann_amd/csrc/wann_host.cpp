@@ -153,6 +153,8 @@ struct wann_index {
   DevBuf<float> d_pnorm2;
   DevBuf<unsigned int> d_pnorm2_max;
   bool have_norms = false;
+  int dense_idle = 0;            // batches in a row on which the dense path found no window group (run_batch)
+  uint32_t dense_batches = 0;
   DevBuf<GemmGroup> g_groups;
   DevBuf<int32_t> g_gq, g_tile_group, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan;
   DevBuf<unsigned long long> g_slot_key, g_score_used;
@@ -558,8 +560,17 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     HIP_CHECK(hipEventRecord(W.ev_route, st));
   }
 
-  if (I.host().spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.host().spec.dtype == WANN_DTYPE_F32 && !getenv("WANN_NO_GEMM"))
+  // The dense path is an optimisation for batches in which queries SHARE windows; on a stream of batches that never form a
+  // group its six launches are 30 - 45 us of nothing per batch (a tenth of a 2^-12-window batch).  After two such batches in a
+  // row it is only tried every eighth batch until one forms a group again (WANN_DENSE_ALWAYS: every batch).  Results do not
+  // depend on it: what the dense path does not take goes through the exact scan.
+  bool tried_dense = false;
+  if (I.host().spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.host().spec.dtype == WANN_DTYPE_F32 && !getenv("WANN_NO_GEMM") &&
+      (I.dense_idle < 2 || (I.dense_batches & 7) == 0 || getenv("WANN_DENSE_ALWAYS"))) {
     dense_prefilter(I, d_queries, nq, k, st);
+    tried_dense = true;
+  }
+  I.dense_batches++;
 
   const bool may_brute = I.host().spec.kind != WANN_KIND_POSTFILTER && I.host().spec.kind != WANN_KIND_SUPER;
   if (may_brute) {
@@ -941,6 +952,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   I.last.rounds = rounds;
   I.last.recovered_continuations = recovered;
   I.last.gemm_queries = (int64_t)W.h_ctr->gemm_queries;
+  if (tried_dense) I.dense_idle = W.h_ctr->gemm_queries ? 0 : I.dense_idle + 1;
   I.last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
   I.last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
   I.last.deep_handoffs = (int64_t)W.h_ctr->deep_handoffs;

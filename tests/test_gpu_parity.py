@@ -784,6 +784,40 @@ def test_dense_prefilter_matches_oracle(oracle, wa, gpu, monkeypatch, metric, sf
         assert np.array_equal(ids, ids2) and np.array_equal(dists, dists2)
 
 
+def test_dense_prefilter_is_skipped_on_streams_without_shared_windows(wa, gpu, monkeypatch):
+    """After two batches in a row without any window group the dense path is only tried every eighth batch (its launches are a
+    tenth of a tiny-window batch); when shared windows come back it picks up again.  Rows never depend on which path ran."""
+    rng = np.random.default_rng(23)
+    n, d, nq = 30000, 32, 400
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    labels = rng.permutation(n).astype(np.float32)
+    pi = wa.PrefilterIndexFloatEuclidian(X, labels)
+    distinct = np.stack([np.arange(nq) * 10.0 + 0.5, np.arange(nq) * 10.0 + 3000.5], 1)  # 3 000 points each, all different
+    shared = np.tile(np.array([[100.5, 9100.5]]), (nq, 1))
+    monkeypatch.setenv("WANN_NO_GEMM", "1")
+    want_d = pi.batch_search(Q, distinct, nq, _qp(wa, 10, 1, 10))
+    want_s = pi.batch_search(Q, shared, nq, _qp(wa, 10, 1, 10))
+    monkeypatch.delenv("WANN_NO_GEMM")
+    for _ in range(3):
+        got = pi.batch_search(Q, distinct, nq, _qp(wa, 10, 1, 10))
+        assert pi.counters()["gemm_queries"] == 0
+        assert np.array_equal(got[0], want_d[0]) and np.array_equal(got[1], want_d[1])
+    dense = []
+    for _ in range(10):
+        got = pi.batch_search(Q, shared, nq, _qp(wa, 10, 1, 10))
+        dense.append(pi.counters()["gemm_queries"])
+        assert np.array_equal(got[0], want_s[0]) and np.array_equal(got[1], want_s[1])
+    assert dense[0] == 0 and max(dense) == nq, dense          # skipped at first, picked up within eight batches ...
+    assert dense[dense.index(nq):] == [nq] * (10 - dense.index(nq)), dense  # ... and then on every batch
+    monkeypatch.setenv("WANN_DENSE_ALWAYS", "1")
+    pi2 = wa.PrefilterIndexFloatEuclidian(X, labels)
+    for _ in range(3):
+        pi2.batch_search(Q, distinct, nq, _qp(wa, 10, 1, 10))
+    pi2.batch_search(Q, shared, nq, _qp(wa, 10, 1, 10))
+    assert pi2.counters()["gemm_queries"] == nq
+
+
 @pytest.mark.parametrize("sfx,d,style", [("FloatMips", 100, "unit"), ("FloatEuclidian", 128, "sift"), ("FloatEuclidian", 24, "unit"),
                                          ("FloatMips", 7, "drift"), ("FloatMips", 512, "unit"), ("FloatEuclidian", 260, "unit")])
 def test_dense_prefilter_slices_and_tiles(wa, gpu, monkeypatch, sfx, d, style):

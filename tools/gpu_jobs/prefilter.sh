@@ -1,5 +1,5 @@
 #!/bin/bash
 O=gpurun_out/prefilter
 mkdir -p $O
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-WANN_PF_NO_REF=1 WANN_PF_DIM=512 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof512 -- python3 tools/bench_prefilter.py > $O/b512.json 2> $O/b512.err
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "prefilter or dense or gemm" > $O/tests.log 2>&1
+WANN_PF_NO_REF=1 python tools/bench_prefilter.py > $O/bench.json 2> $O/bench.err

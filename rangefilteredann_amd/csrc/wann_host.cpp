@@ -599,7 +599,11 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       ba.part_cap = (int64_t)part_cap;
       ba.part_slots = (int64_t)part_slots;
     }
-    int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * 4, (nq * std::min(maxt, 2) + kWavesPerBlock - 1) / kWavesPerBlock);
+    // (as many waves as the chip holds at once -- by the registers: two per SIMD for squared-L2 float rows (two 512-byte rows
+    // per lane pair in flight), three for inner-product float rows, five for byte rows -- deal the tickets among themselves)
+    const int brute_per_cu = getenv("WANN_BRUTE_PER_CU") ? std::max(1, atoi(getenv("WANN_BRUTE_PER_CU")))  // dev knob
+                             : (I.view.dtype != WANN_DTYPE_F32 ? 5 : (I.view.metric == 1 ? 3 : 2));
+    int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * brute_per_cu, (nq * std::min(maxt, 2) + kWavesPerBlock - 1) / kWavesPerBlock);
     if (launch_brute(ba, blocks, st)) throw HipError(std::string("k_brute: ") + launch_last_error());
   }
 

@@ -324,6 +324,14 @@ def main():
             if best_ok is not None and first["wall_ms"] > 3 * best_ok:
                 break
         ok = [r for r in rows if r["recall"] > 0.95]
+        # one timed run per setting is noisy where two settings are within a few per cent of each other (2^-8: (40, x1),
+        # (80, x1), (160, x1)): the three fastest are timed three more times each before one is picked
+        for r in sorted(ok, key=lambda r: r["wall_ms"])[:3]:
+            for _ in range(3):
+                t = time.perf_counter()
+                run(Wt, r["beam"], r["mult"])
+                r["wall_ms"] = min(r["wall_ms"], (time.perf_counter() - t) * 1e3)
+                r["device_ms"] = min(r["device_ms"], index.counters()["device_ms"])
         best = min(ok, key=lambda r: r["wall_ms"]) if ok else None
         return Wg, Wgt, rows, best
 

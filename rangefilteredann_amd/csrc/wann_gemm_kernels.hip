@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
   constexpr int RB = 4 * W + 16;     // bytes per staged point and slab
   unsigned char *Ps = smem;                                    // [128][RB]
   float *base = reinterpret_cast<float *>(smem + 128 * RB);    // [128] per staged point: |p|^2 / 0
-  int *rid = reinterpret_cast<int *>(base + 128);              // [128] point rows of the step being fetched
+  int *rid = reinterpret_cast<int *>(base + 128);              // [128] point rows of the step being fetched (+ a second [128], see below)
   // four slabs: the low halves of the LAST slab's A operand live in the LDS (8 KiB per wave; a lane reads its own 16 bytes):
   // 32 registers that operands, accumulators and the block in flight do not have
   constexpr int SR = SLABS == 4 ? 3 : SLABS;  // slabs whose low halves stay in registers
@@ -533,18 +533,23 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
     constexpr bool PIPE = SLABS < 4;
     if (PIPE) WANN_FETCHW(p_begin, 0, true)
     f32x16 acc[4];
+    // Not pipelined (four slabs): every slab of a step reads the step's rows from `rid` while it stages, and the only barrier
+    // between the last slab's reads and the hand-over of the next step's rows would be the one that ENDED the slab before --
+    // a wave that lags by one gather would stage the next step's points for this step.  The rows therefore alternate between
+    // two arrays by step parity: the last slab writes the array nobody reads until the step-ending barrier has passed.
+    int *rid_cur = rid, *rid_nxt = PIPE ? rid : rid + 128;
     for (int64_t c0 = p_begin; c0 < p_end; c0 += 128) {
 #pragma unroll
       for (int sl = 0; sl < SLABS; sl++) {
-        // (the barrier that ended the previous slab: nobody reads Ps / base / rid any more)
-        if (!PIPE && sl == 0 && tid < 128) {  // (rid = this step's rows; pre_rid = the next step's, taken over at the last slab)
-          pre_n = A.pnorm2[rid[tid]];
+        // (the barrier that ended the previous slab: nobody reads Ps / base any more)
+        if (!PIPE && sl == 0 && tid < 128) {  // (rid_cur = this step's rows; pre_rid = the next step's, published at the last slab)
+          pre_n = A.pnorm2[rid_cur[tid]];
           pre_rid = ix.fi_sorted[grp.a + min(c0 + 128 + tid, wlast)];
         }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
           if (!PIPE) {  // fetch and stage half a slab at a time: 32 registers in flight instead of 64
-            const float *src = ix.points + (int64_t)rid[64 * p + (tid >> 2)] * stride;
+            const float *src = ix.points + (int64_t)rid_cur[64 * p + (tid >> 2)] * stride;
 #pragma unroll
             for (int x = 0; x < nx; x++) pre[p * nx + x] = *reinterpret_cast<const f32x4 *>(src + min(W * sl + 4 * (tid & 3) + 16 * x, stride - 4));
           }
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
         }
         if (tid < 128) {
           if (sl == 0) base[tid] = (c0 + tid < p_end) ? (mips ? 0.f : pre_n) : kHuge;  // positions beyond the window never win
-          if (sl == SLABS - 1) rid[tid] = pre_rid;
+          if (sl == SLABS - 1) rid_nxt[tid] = pre_rid;
         }
         __syncthreads();
         if (PIPE) {
@@ -615,7 +620,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
           }
         }
       if (live) erow[(c0 - p_begin) >> 6] = f32x4{m1, m2, m3, m4};
-      __syncthreads();  // every wave is done with Ps / base / rid
+      __syncthreads();  // every wave is done with Ps / base / this step's rows
+      if (!PIPE) {
+        int *const t = rid_cur;
+        rid_cur = rid_nxt;
+        rid_nxt = t;
+      }
     }
   }
 #undef WANN_FETCHW

@@ -25,6 +25,7 @@
 #include "wann_gemm_device.h"
 #include "wann_gpu_build.h"
 #include "wann_hip_util.h"
+#include "wann_tuning.h"
 
 using namespace wann;
 
@@ -163,6 +164,8 @@ struct wann_index {
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
   wann_counters last{};
+  // every WANN_* switch, read when the index is created (wann_tuning.h); run_batch never reads the environment
+  Tuning tune;
   std::mutex mu;
   ~wann_index() {
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -352,7 +355,7 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   const int waves_per_cu = (I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32) ? 12 : 8;
   int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, (160 * 1024) / per_block);
   blocks_per_cu = std::max(1, blocks_per_cu);
-  if (const char *e = getenv("WANN_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(e)));  // dev knob
+  if (I.tune.blocks_per_cu > 0) blocks_per_cu = std::max(1, std::min(blocks_per_cu, I.tune.blocks_per_cu));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
   const int cap_bits = hash_bits(cap);
   if (force_table || cap_bytes + ((int64_t)4 << cap_bits) > usable) {  // some beam of the range keeps its filter in global memory
@@ -380,7 +383,7 @@ int lean_pool_bytes(const wann_index &I) {
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
   // (a workgroup's LDS is allocated in 1 KiB steps at most: 53 KiB per workgroup, three of them in 160 KiB)
   int pool = (53 * 1024) / kWavesPerBlock - common;
-  if (const char *e = getenv("WANN_LEAN_POOL")) pool = atoi(e);  // dev knob
+  if (I.tune.lean_pool > 0) pool = I.tune.lean_pool;  // dev knob
   return pool >= kInKernelBeamCap * 8 + 1536 ? pool : 0;
 }
 
@@ -452,7 +455,8 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
   // fp32 accumulation of the 3 d exact bf16 x bf16 products of a score: worst case (3 d) u |q||p| for ANY order of the
   // additions, u = 2^-24 with a rounding adder, 2^-23 with a truncating one; 3 = the truncating bound and half as much again.
   // (Round 2 used 8: at d = 512 that one term was 7.4e-4 |q||p|, 46 % of the adversarial queries could not be proven.)
-  ga.acc_factor = getenv("WANN_PROOF_FACTOR") ? (float)atof(getenv("WANN_PROOF_FACTOR")) : 3.f;  // (dev knob)
+  // The knob can only widen the margin (Tuning clamps it to >= 3): a smaller factor would certify unproven results.
+  ga.acc_factor = I.tune.proof_factor;
   ga.out_key = W.out_key.p;
   ga.out_cnt = W.out_cnt.p;
   ga.brute_list = W.list_brute.p;
@@ -489,7 +493,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   // multi-bucket fenwick cover, which cannot happen for split <= 4 without a ratio: SURVEY.md A.5)
   const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.host().spec.split_factor <= 4);
   const int maxt = single ? 1 : 96;
-  const bool spec = I.host().vamana_leaves && !getenv("WANN_NO_SPEC");
+  const Tuning &T = I.tune;
+  const bool spec = I.host().vamana_leaves && T.spec;
   const int64_t sub_slots = spec ? std::min<int64_t>(nq * (int64_t)maxt * 4 + 1024, (int64_t)1 << 26) : 0;
   W.ensure(nq, k, maxt, sub_slots);
   if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
@@ -520,16 +525,16 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   ra.graph_count = W.ints.p + I_GRAPH_COUNT;
   ra.heavy_list = W.list_heavy.p;
   ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
-  ra.prio_count = getenv("WANN_NO_EVIDENCE_FIRST") ? nullptr : W.ints.p + I_PRIO_COUNT;
+  ra.prio_count = T.evidence_first ? W.ints.p + I_PRIO_COUNT : nullptr;
   ra.heavy_cap = W.big_stride;
   ra.mid_list = W.list_mid.p;
   ra.mid_count = W.ints.p + I_MID_COUNT;
-  ra.heavy_ratio = getenv("WANN_HEAVY_RATIO") ? atoi(getenv("WANN_HEAVY_RATIO")) : 8;
+  ra.heavy_ratio = T.heavy_ratio;
   ra.risk_count = W.ints.p + I_RISK;
   ra.brute_list = W.list_brute.p;
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
   ra.spec = spec ? 1 : 0;
-  ra.spec_num = getenv("WANN_SPEC_NUM") ? atoi(getenv("WANN_SPEC_NUM")) : 8;
+  ra.spec_num = T.spec_num;
   ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp.beam_width);
   ra.sub_base0 = (int32_t)(nq * maxt);
   ra.sub_cap = (int32_t)(nq * maxt + sub_slots);
@@ -538,7 +543,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   // the LDS of all four waves), beams up to big_cap (the LDS beam must fit; 5792^2 < 2^25 bounds the filter
   // at 32 MiB per workgroup)
   int32_t big_cap = 0;
-  if (spec && !getenv("WANN_NO_BIG")) {
+  if (spec && T.big) {
     const int common = search_lds_bytes_per_wave(I.view.stride, 0);
     const int64_t big_pool = (int64_t)(common + kSearchPoolBytes) * kWavesPerBlock - common;
     big_cap = (int32_t)std::min<int64_t>(big_pool / 8, 5792);
@@ -565,8 +570,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   // row it is only tried every eighth batch until one forms a group again (WANN_DENSE_ALWAYS: every batch).  Results do not
   // depend on it: what the dense path does not take goes through the exact scan.
   bool tried_dense = false;
-  if (I.host().spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.host().spec.dtype == WANN_DTYPE_F32 && !getenv("WANN_NO_GEMM") &&
-      (I.dense_idle < 2 || (I.dense_batches & 7) == 0 || getenv("WANN_DENSE_ALWAYS"))) {
+  if (I.host().spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.host().spec.dtype == WANN_DTYPE_F32 && T.gemm &&
+      (I.dense_idle < 2 || (I.dense_batches & 7) == 0 || T.dense_always)) {
     dense_prefilter(I, d_queries, nq, k, st);
     tried_dense = true;
   }
@@ -585,7 +590,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     ba.out_key = W.out_key.p;
     ba.out_cnt = W.out_cnt.p;
     ba.ctr = W.ctr.p;
-    if (!getenv("WANN_NO_SPLIT_SCAN")) {
+    if (T.split_scan) {
       const size_t part_cap = (size_t)4 << 20, part_slots = 8192;  // 32 MiB of partial lists
       // (a list is only split while it has far fewer entries than there are waves)
       W.part_key.ensure(part_cap);
@@ -601,7 +606,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     }
     // (as many waves as the chip holds at once -- by the registers: two per SIMD for squared-L2 float rows (two 512-byte rows
     // per lane pair in flight), three for inner-product float rows, five for byte rows -- deal the tickets among themselves)
-    const int brute_per_cu = getenv("WANN_BRUTE_PER_CU") ? std::max(1, atoi(getenv("WANN_BRUTE_PER_CU")))  // dev knob
+    const int brute_per_cu = T.brute_per_cu > 0 ? T.brute_per_cu  // dev knob
                              : (I.view.dtype != WANN_DTYPE_F32 ? 5 : (I.view.metric == 1 ? 3 : 2));
     int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * brute_per_cu, (nq * std::min(maxt, 2) + kWavesPerBlock - 1) / kWavesPerBlock);
     if (launch_brute(ba, blocks, st)) throw HipError(std::string("k_brute: ") + launch_last_error());
@@ -627,8 +632,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.mult = (int32_t)std::min<int64_t>(qp.final_beam_multiply, INT32_MAX);
     sa.max_beam = (int32_t)qp.postfiltering_max_beam;
     sa.pool_bytes = kSearchPoolBytes;
-    sa.force_general = getenv("WANN_FORCE_GENERAL") ? 1 : 0;
-    sa.search_prio = getenv("WANN_SEARCH_PRIO") ? atoi(getenv("WANN_SEARCH_PRIO")) : 0;  // dev knob
+    sa.force_general = T.force_general ? 1 : 0;
+    sa.search_prio = T.search_prio;  // dev knob
     sa.out_key = W.out_key.p;
     sa.out_cnt = W.out_cnt.p;
     sa.ctr = W.ctr.p;
@@ -638,7 +643,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.sub_cmps = W.sub_cmps.p;
     sa.next_beam = W.next_beam.p;
     DevBuf<long long> d_trace;  // dev tool: WANN_TASK_TRACE=<file> dumps one line per beam search
-    const char *trace_path = getenv("WANN_TASK_TRACE");
+    const char *trace_path = T.task_trace.empty() ? nullptr : T.task_trace.c_str();
     const size_t trace_cap = (size_t)1 << 20;
     if (trace_path) {
       d_trace.ensure(1 + 4 * trace_cap);
@@ -647,25 +652,19 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     }
     // Continuation pollers need the two launches resident together; with launches known to be serialised they are
     // not used at all (continuations then go to the follow-up launch directly).
-    auto env_on = [](const char *name) {
-      const char *v = getenv(name);
-      return v && *v && strcmp(v, "0") != 0;
-    };
-    const bool use_pollers = !getenv("WANN_NO_POLLERS") &&
-                             (getenv("WANN_FORCE_POLLERS") /* test hook */ ||
-                              (!env_on("HIP_LAUNCH_BLOCKING") && !env_on("AMD_SERIALIZE_KERNEL") && !env_on("CUDA_LAUNCH_BLOCKING")));
+    const bool use_pollers = T.pollers && (T.force_pollers /* test hook */ || !T.serialized);
     int64_t max_part = 1;
     for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
-    sa.old_general = getenv("WANN_OLD_GENERAL") ? 1 : 0;
+    sa.old_general = T.old_general ? 1 : 0;
     // (idle pollers look for chains that will outgrow their speculated levels: on unless WANN_SCAN=0)
-    const bool scan_on = spec && !(getenv("WANN_SCAN") && atoi(getenv("WANN_SCAN")) == 0) && !getenv("WANN_NO_LOOKAHEAD");
+    const bool scan_on = spec && T.scan && T.lookahead;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0,
                       int base_pool = kSearchPoolBytes) {
       RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0, a.old_general != 0, base_pool);
       big_lds = rc.big_lds;
       a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
-      a.helper = (rc.lc.big == 1 && !getenv("WANN_NO_HELPER")) ? kHelpers : 0;
+      a.helper = (rc.lc.big == 1 && T.helper) ? kHelpers : 0;
       a.B = (int32_t)first_beam;
       a.cap_inkernel = (int32_t)cap;
       a.pool_bytes = rc.pool_bytes;
@@ -688,13 +687,12 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         const int common = search_lds_bytes_per_wave(I.view.stride, 0);
         big = a;
         big_lc.big = a.old_general ? 2 : 1;  // (WANN_OLD_GENERAL: the first-generation core also for the companion's searches)
-        big.helper = (big_lc.big == 2 || getenv("WANN_NO_HELPER")) ? 0 : kHelpers;
+        big.helper = (big_lc.big == 2 || !T.helper) ? 0 : kHelpers;
         big.cap_inkernel = with_big_cap;
         big.pool_bytes = (common + kSearchPoolBytes) * kWavesPerBlock - common;
         // A companion workgroup of this size shares its CU with an ordinary one (80 KB of LDS and <= 256 registers each).
         // The few pollers of a launch without big items (deep chains) are worth a CU each: they book its whole LDS.
-        const char *ex = getenv("WANN_BIG_EXCLUSIVE");
-        if (ex ? atoi(ex) != 0 : deep_pollers > 0) big.pool_bytes = 150 * 1024 - common;
+        if (T.big_exclusive >= 0 ? T.big_exclusive != 0 : deep_pollers > 0) big.pool_bytes = 150 * 1024 - common;
         big.big_list = W.list_big.p;
         big.big_count = W.ints.p + I_BIG_COUNT;
         big.big_stride = W.big_stride;
@@ -708,14 +706,14 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         big.g_epoch = W.g_epoch_big.p;
         big.g_seen = W.g_seen_big.p;
         big.g_seen_words = seen_words;
-        a.yield_for_big = getenv("WANN_NO_YIELD") ? 0 : 1;
+        a.yield_for_big = T.yield ? 1 : 0;
         a.big_resident = big.big_resident = W.ints.p + I_BIG_RESIDENT;
         a.big_count = W.ints.p + I_BIG_COUNT;
         if (use_pollers) {
           // (companion workgroups share their CUs: pollers are cheap; with the scan on, idle ones look for chains that need a look-ahead)
-          a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : (getenv("WANN_POLLERS") ? std::max(1, atoi(getenv("WANN_POLLERS"))) : (scan_on ? 32 : 16));
+          a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : (T.npollers > 0 ? T.npollers : (scan_on ? 32 : 16));
           if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
-          if (spec && !getenv("WANN_NO_LOOKAHEAD")) {  // look-ahead searches for chains that keep failing (k_search)
+          if (spec && T.lookahead) {  // look-ahead searches for chains that keep failing (k_search)
             a.la_count = big.la_count = W.ints.p + I_SUB_COUNT;
             a.la_base0 = big.la_base0 = (int32_t)(nq * maxt);
             a.la_cap = big.la_cap = (int32_t)std::min<int64_t>(nq * maxt + sub_slots, INT32_MAX);
@@ -724,15 +722,15 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
             if (deep_pollers == 0 && scan_on) {  // (companion mode: there are speculating tasks)
               big.scan_list = W.list_big.p + 3 * (size_t)W.big_stride;
               big.scan_count = W.ints.p + I_SCAN_COUNT;
-              big.scan_min_top = getenv("WANN_SCAN_MIN_TOP") ? atoi(getenv("WANN_SCAN_MIN_TOP")) : 2560;
-              big.scan_num = getenv("WANN_SCAN_NUM") ? atoi(getenv("WANN_SCAN_NUM")) : 16;
+              big.scan_min_top = T.scan_min_top;
+              big.scan_num = T.scan_num;
             }
-            if (getenv("WANN_LA_EAGER")) {  // test hook: every chain that fails its second level asks for one
+            if (T.la_eager) {  // test hook: every chain that fails its second level asks for one
               a.la_min_beam = big.la_min_beam = (int32_t)(2 * first_beam);
               a.la_found_max = big.la_found_max = (int32_t)qp.k;
             }
           }
-          big.force_poll_timeout = getenv("WANN_FORCE_POLL_TIMEOUT") ? 1 : 0;  // test hook
+          big.force_poll_timeout = T.force_poll_timeout ? 1 : 0;  // test hook
           a.big_cap = big.big_cap = with_big_cap;  // (the companion's own chains ask for look-aheads too)
           a.big_count = W.ints.p + I_BIG_COUNT;
           a.dyn_list = big.dyn_list = W.list_big.p + 2 * (size_t)W.big_stride;
@@ -786,7 +784,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     sa.heavy_count = W.ints.p + I_HEAVY_COUNT;
     // longest searches first (k_order_heavy) where a launch has levels of several milliseconds: those in the companion launch
     // tell (2^-7 ... 2^-9 of SIFT-1M: 1 ms less per batch; at the wide windows the order of query numbers is as good)
-    if (big_n > 0 && W.h_ints[I_HEAVY_COUNT] >= 256 && !getenv("WANN_NO_ORDER")) {
+    if (big_n > 0 && W.h_ints[I_HEAVY_COUNT] >= 256 && T.order) {
       OrderArgs oa{W.tasks.p, W.list_heavy.p, W.list_heavy_ordered.p, W.ints.p + I_HEAVY_COUNT};
       if (launch_order_heavy(oa, st)) throw HipError(std::string("k_order_heavy: ") + launch_last_error());
       sa.heavy_list = W.list_heavy_ordered.p;
@@ -804,16 +802,16 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
     const bool may_continue = W.h_ints[I_RISK] > 0 && use_pollers;
     // A saturated launch without any of that still ends with its few longest chains (a third doubling level started at
     // 1.5 ms of a 2.7 ms bulk runs 1.5 ms there, 0.4 ms alone): a handful of pollers, a CU each, take such chains over.
-    const int64_t deep_min = getenv("WANN_DEEP_MIN_TASKS") ? atoll(getenv("WANN_DEEP_MIN_TASKS")) : 4096;
+    const int64_t deep_min = T.deep_min_tasks;
     int32_t deep = 0;
     // (worth a second launch only for a launch of a few milliseconds: tasks x first beam ~ hops)
     if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && graph_n * b0 >= deep_min * 150 &&
-        !getenv("WANN_NO_DEEP") && std::max<int64_t>(4 * b0, 256) <= cap1)
-      deep = getenv("WANN_DEEP_POLLERS") ? std::max(1, atoi(getenv("WANN_DEEP_POLLERS"))) : 4;
+        T.deep && std::max<int64_t>(4 * b0, 256) <= cap1)
+      deep = T.deep_pollers;
     // Three workgroups per CU (a leaner LDS pool) where the kernel allows it and no companion workgroup has to share a CU with
     // the ordinary ones (the deep-chain pollers book whole CUs of their own)
     int base_pool = kSearchPoolBytes;
-    if (big_n == 0 && !may_continue && !getenv("WANN_NO_LEAN") && cap1 == kInKernelBeamCap && lean_pool_bytes(I) > 0) base_pool = lean_pool_bytes(I);
+    if (big_n == 0 && !may_continue && T.lean && cap1 == kInKernelBeamCap && lean_pool_bytes(I) > 0) base_pool = lean_pool_bytes(I);
     launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue || deep > 0) ? big_cap : 0, deep, base_pool);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -834,7 +832,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         HIP_CHECK(hipMemcpyAsync(W.ints.p + I_NEXT0, &next_n, 4, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipStreamSynchronize(st));  // `unserved` / next_n back the uploads
         recovered = (int64_t)unserved.size();
-        if (getenv("WANN_VERBOSE")) fprintf(stderr, "[wann batch] %d continuations not served by the pollers: re-queued\n", (int)unserved.size());
+        if (T.verbose) fprintf(stderr, "[wann batch] %d continuations not served by the pollers: re-queued\n", (int)unserved.size());
       }
     }
     // launch 2 (rare): the tasks that must double beyond the cap finish their loop in huge mode
@@ -902,7 +900,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
         fclose(f);
       }
     }
-    if (getenv("WANN_VERBOSE")) {
+    if (T.verbose) {
       HIP_CHECK(hipStreamSynchronize(st));
       fprintf(stderr, "[wann batch] beam %ld x%ld: next %d final %d big %d+%d heavy %d;", (long)qp.beam_width, (long)qp.final_beam_multiply,
               next_n, final_n, W.h_ints[I_BIG_COUNT], W.h_ints[I_BIG_COUNT + 1], W.h_ints[I_HEAVY_COUNT]);
@@ -1004,7 +1002,7 @@ void build_pending(wann_index &I, std::vector<HostPart *> &pending) {
         break;
       } catch (std::runtime_error &e) {
         if (std::string(e.what()).find("gpu build overflow: a visited list") == std::string::npos || vis_scale >= 8) throw;
-        if (getenv("WANN_VERBOSE")) fprintf(stderr, "[wann] %s; restarting the GPU build with a %dx buffer\n", e.what(), 2 * vis_scale);
+        if (I.tune.verbose) fprintf(stderr, "[wann] %s; restarting the GPU build with a %dx buffer\n", e.what(), 2 * vis_scale);
       }
     }
   }
@@ -1075,6 +1073,7 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
   try {
     I->device = device;
     I->dtype = dtype;
+    I->tune = Tuning::from_env();
     I->H.spec = make_spec(kind, metric, dtype, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
     std::vector<HostPart *> pending;
     build_host_index(I->H, points, labels, -1, 0, &pending);
@@ -1111,6 +1110,7 @@ wann_index *wann_index_create(int kind, int metric, int dtype, const void *point
       R->Hp = &I->H;
       R->device = dv;
       R->dtype = dtype;
+      R->tune = I->tune;
       upload_index(*R);
       I->replicas.push_back(std::move(R));
     }
@@ -1136,6 +1136,7 @@ int wann_batch_search_device(wann_index *I, const void *d_queries, const float *
     // NULL = the HIP default stream: ordered after everything the caller queued on its default stream
     // (torch's current stream unless changed), so freshly produced inputs / recycled output blocks are safe
     hipStream_t st = (hipStream_t)hip_stream;
+    if (I->tune.hooks_live) I->tune = Tuning::from_env();  // WANN_TEST_HOOKS=1 only: tests flip switches between batches
     run_batch(*I, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st);
   } catch (HipError &e) {
     return fail(WANN_ERR_HIP, e.what());
@@ -1151,6 +1152,7 @@ void search_host_one(wann_index &T, const void *queries, const float *ranges, in
                      const wann_query_params &qp, uint32_t *ids, float *dists) {
   std::lock_guard<std::mutex> lk(T.mu);
   HIP_CHECK(hipSetDevice(T.device));
+  if (T.tune.hooks_live) T.tune = Tuning::from_env();  // WANN_TEST_HOOKS=1 only
   Workspace &W = T.ws;
   const int64_t d = T.host().spec.d;
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
@@ -1327,6 +1329,7 @@ struct RawGraph {
             int64_t subset_start, int64_t subset_n_, int dtype = WANN_DTYPE_F32) {
     HIP_CHECK(hipSetDevice(device));
     I.device = device;
+    I.tune = Tuning::from_env();
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     I.num_cus = prop.multiProcessorCount;
@@ -1388,9 +1391,11 @@ struct RawGraph {
     d_ctr.ensure(1);
     HIP_CHECK(hipMemset(d_ctr.p, 0, sizeof(Counters)));
     const bool with_cut = cut_k > 0;
-    const bool old_general = getenv("WANN_OLD_GENERAL") != nullptr || with_cut, force_general = getenv("WANN_FORCE_GENERAL") != nullptr || with_cut;
+    if (I.tune.hooks_live) I.tune = Tuning::from_env();  // (tests flip the core switches between calls on one VamanaIndex)
+    const Tuning &T = I.tune;
+    const bool old_general = T.old_general || with_cut, force_general = T.force_general || with_cut;
     // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
-    RoundCfg rc = config_for(I, beam, beam, nq, getenv("WANN_RAW_BIG_LDS") != nullptr || old_general, force_general, old_general);
+    RoundCfg rc = config_for(I, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general);
     SearchArgs sa{};
     sa.ix = I.view;
     sa.queries = d_q.p;
@@ -1418,7 +1423,7 @@ struct RawGraph {
     sa.cut_k = (int32_t)cut_k;
     sa.cut = cut;
     sa.old_general = old_general ? 1 : 0;
-    sa.helper = (rc.lc.big == 1 && !getenv("WANN_NO_HELPER")) ? kHelpers : 0;
+    sa.helper = (rc.lc.big == 1 && T.helper) ? kHelpers : 0;
     if (rc.table_bits) {
       const int64_t seen_words = ((subset_n + 127) / 128) * 4;
       ensure_filter_scratch(g_table, g_epoch, g_seen, layout, rc.slots, rc.table_bits, seen_words, nullptr);
@@ -1433,14 +1438,14 @@ struct RawGraph {
       g_beam.ensure((size_t)rc.slots * sa.g_beam_cap);
       sa.g_beam = g_beam.p;
     }
-    const bool prof = getenv("WANN_PROFILE_PHASES") != nullptr;
+    const bool prof = T.profile_phases;
     if (prof) {
       d_prof.ensure(16);
       HIP_CHECK(hipMemset(d_prof.p, 0, 16 * sizeof(unsigned long long)));
       sa.prof = d_prof.p;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool verbose = getenv("WANN_VERBOSE") != nullptr;
+    const bool verbose = T.verbose;
     if (verbose) {
       HIP_CHECK(hipEventCreate(&e0));
       HIP_CHECK(hipEventCreate(&e1));

@@ -944,6 +944,10 @@ __device__ __forceinline__ void score_helper(const IndexView &ix, int32_t *gtabl
       continue;
     }
     const int pnode = vb->req[next & (kReqRing - 1)];
+    // (the search may have ended and the next one published requests between the reads above: `pnode` would then be a node
+    // of ANOTHER partition, and the addresses formed below from this search's row_base / row_off could lie outside the
+    // graph / point allocations -- the packet would be ignored (old generation), the loads would not be harmless)
+    if (vb->gen != my_gen) continue;
     const int sl = next % kPkSlots;
     next += kHelpers;
     if (lane == 0) vb->tag[sl] = 0ull;  // readers of the old packet notice (this wave's LDS operations execute in order)

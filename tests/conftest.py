@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the engine reads its WANN_* switches once per index; tests flip them between batches on one index, and some force rare
+# paths through test-only hooks: both need WANN_TEST_HOOKS=1 (rangefilteredann_amd/csrc/wann_tuning.h)
+os.environ.setdefault("WANN_TEST_HOOKS", "1")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:

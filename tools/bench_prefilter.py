@@ -5,6 +5,7 @@ queries; experiments/generate_advserial_dataset.py:8-69), PrefilterIndex brute f
 each against the REAL reference at its best thread count (child processes: the reference fixes its thread count at first use).
 Run from the repo root.  Prints one JSON object."""
 import json, os, subprocess, sys, time
+os.environ.setdefault("WANN_TEST_HOOKS", "1")  # this tool flips WANN_* switches between calls on one index
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 

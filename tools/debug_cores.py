@@ -1,5 +1,6 @@
 """Dev tool: raw beam search of the product against the oracle over (env, beam, graph flavour); prints mismatch summaries."""
 import os, sys, numpy as np
+os.environ.setdefault("WANN_TEST_HOOKS", "1")  # this tool flips WANN_* switches between calls on one index
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import rangefilteredann_amd, window_ann as wa
 from oracle import oracle

@@ -1,6 +1,7 @@
 """Dev tool: device time and work counters of fixed (beam, mult) settings at given window fractions on the bench index
 (SIFT-1M-like 2-WST).  Usage: python tools/frac_probe.py --fractions=-11,-9,-6 --settings 80,1:160,1 [--n 1000000]"""
 import argparse, os, sys, time
+os.environ.setdefault("WANN_TEST_HOOKS", "1")  # this tool flips WANN_* switches between calls on one index
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np, torch

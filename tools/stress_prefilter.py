@@ -3,6 +3,7 @@ up to 512, clustered and uniform data, near-duplicate points, labels with and wi
 bound of k_rerank decides which queries may skip the exact scan: every row of every batch must equal the scan's.
 Usage: python tools/stress_prefilter.py [seconds]"""
 import os, sys, time
+os.environ.setdefault("WANN_TEST_HOOKS", "1")  # this tool flips WANN_* switches between calls on one index
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np
 import window_ann as wa

@@ -3,6 +3,7 @@ helper-wave packets, pollers, look-aheads, evidence-first order) -- every repeti
 of the first one (which tests/test_gpu_parity.py pins to the oracle).  Timing differs from run to run; results must not.
 Usage: python tools/stress_repeat.py [seconds]"""
 import os, sys, time
+os.environ.setdefault("WANN_TEST_HOOKS", "1")  # this tool flips WANN_* switches between calls on one index
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np
 import window_ann as wa

@@ -1466,8 +1466,8 @@ struct RawGraph {
       HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof h, hipMemcpyDeviceToHost));
       fprintf(stderr, "[wann phases] beam=%ld nq=%ld cycles: row %llu filter %llu dist %llu merge %llu next %llu (built with make PROFILE=1?)\n", (long)beam,
               (long)nq, h[0], h[1], h[2], h[3], h[4]);
-      fprintf(stderr, "[wann phases 5..9] %llu %llu %llu %llu %llu (second-generation core: select / row+probes / next+requests / slot test / filter / "
-                      "next packet / distances / delta insert / truncation)\n", h[5], h[6], h[7], h[8], h[9]);
+      fprintf(stderr, "[wann phases 5..8] %llu %llu %llu %llu (second-generation core: select / row+probes / next+requests / slot test / filter / "
+                      "next packet / distances / delta insert / truncation); probe wait %llu, flush %llu\n", h[5], h[6], h[7], h[8], h[9], h[10]);
     }
     HIP_CHECK(hipMemcpy(out_ids, d_rid.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_dists, d_rd.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));

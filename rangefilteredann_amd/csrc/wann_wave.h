@@ -20,6 +20,9 @@ typedef unsigned long long u64;
 #define WANN_PROF_PTR(p) ((unsigned long long *)nullptr)
 #endif
 
+#ifndef WANN_AB
+#define WANN_AB 0  // dev: same-box A/B builds (make EXTRA=-DWANN_AB=n)
+#endif
 #define WANN_LIKELY(x) __builtin_expect(!!(x), 1)
 #define WANN_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
@@ -578,11 +581,14 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
     // number of inserted candidates whose position is <= its index: the candidates at or before the
     // chunk's first index shift the whole chunk (one ballot), the few landing inside it a suffix.
     const bool ndl = mine && !dup;
-    for (int top = p0 + ((span - 1) & ~63); top >= p0; top -= 256) {
-      u64 ev[4];
-      int nx[4];
+    // (a presorted list is the one-wave kernel's delta list going into a beam of thousands: eight chunks per step -- the two
+    // LDS round trips of a step are what the shift waits for, and that kernel has the registers)
+    constexpr int NCH = PRESORTED ? 8 : 4;
+    for (int top = p0 + ((span - 1) & ~63); top >= p0; top -= 64 * NCH) {
+      u64 ev[NCH];
+      int nx[NCH];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < NCH; j++) {
         const int base = top - 64 * j;
         nx[j] = B;  // "do not write"
         ev[j] = 0ull;
@@ -600,7 +606,7 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
       }
       WAVE_SYNC();
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int j = 0; j < NCH; j++)
         if (nx[j] < B) beam[nx[j]] = ev[j];
       WAVE_SYNC();
     }
@@ -882,6 +888,11 @@ __device__ __forceinline__ u64 wave_shr1(u64 v) {  // lane i receives lane i-1's
 // Request i (a node) is served by helper i % kHelpers into packet slot i % kPkSlots; the search wave keeps the
 // slot -> node map in a register, so finding a packet costs no memory access.
 // --------------------------------------------------------------------------------------------
+// Scope of the exact seen set's probes and updates.  Only the waves of ONE workgroup (the search wave and its helper waves: one
+// CU, one L1, one L2) ever touch a search's bitmap, so workgroup scope is enough -- and it matters: a device-scope atomic on a
+// chip with one L2 per XCD is performed beyond the L2 (fabric / memory side, > 1 us), and since a wave's vector-memory counter
+// retires in order every later load of the hop waited behind it.
+constexpr int kSeenScope = __HIP_MEMORY_SCOPE_WORKGROUP;
 constexpr int kPkSlots = 12;
 constexpr int kReqRing = 16;
 static_assert(kPkSlots % kHelpers == 0 && kReqRing >= kPkSlots, "request -> helper / slot mapping");
@@ -959,7 +970,7 @@ __device__ __forceinline__ void score_helper(const IndexView &ix, int32_t *gtabl
     int touch = 0;
     if (valid) {
       touch = gtable[loc];  // the search wave's filter probe will hit the L2
-      w = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, kSeenScope);
     }
     // do two valid lanes of the row share a filter slot?  (exact, by `bits` ballots: this wave is not on the critical path)
     u64 eq = ballot64(valid);
@@ -1112,7 +1123,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   const u64 key0 = (u64)fkey(d0) << 32;
   if (lane == 0) {
     mb[0] = key0;
-    __hip_atomic_fetch_or(gseen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_or(gseen, 1u, __ATOMIC_RELAXED, kSeenScope);
     if (box) vb->gen = my_gen;  // (after the seen set's clear: the helpers read it)
   }
   WAVE_SYNC();
@@ -1203,7 +1214,108 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     resync(pm < p0 ? pm : p0);
   };
 
-  unsigned long long tp = 0, acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // ---- Into the delta list: the keys of the lanes flagged in pm (c of them, D + c <= 64; a computed candidate is always new,
+  //      so all keys are distinct).  ONE pass over the candidates gives every list entry the number of candidates below it
+  //      and every candidate the number of list entries and of other candidates below it -- i.e. everybody's place --, one trip
+  //      through the merge scratch moves everything (a DPP shift of the whole list per candidate before: 45 instructions
+  //      each, this pass: 14).
+  auto delta_insert = [&](u64 pm, u64 key, bool pass) {
+    const int c = popc64(pm);
+    const u64 dk1 = dk | 1ull, key1 = key | 1ull;
+    int shift = 0, below = 0, rank = 0;
+    for (u64 mm = pm; mm; mm &= mm - 1) {
+      const int i = ctz64(mm);
+      const u64 k1 = rdlane64(key, i) | 1ull;
+      const bool gt = dk1 > k1;  // (empty lanes hold ~0: true)
+      shift += gt ? 1 : 0;
+      const int less = 64 - popc64(ballot64(gt));  // list entries below candidate i
+      below = (lane == i) ? less : below;
+      rank += (key1 > k1) ? 1 : 0;
+    }
+    if (lane < D) L.cand_key[lane + shift] = dk;
+    if (pass) L.cand_key[below + rank] = key;
+    WAVE_SYNC();
+    D += c;
+    dk = lane < D ? L.cand_key[lane] : ~0ull;
+    WAVE_SYNC();
+    const u64 du = ballot64(!(dk & 1ull));  // (empty lanes hold ~0: bit 0 set)
+    dhead = du ? rdlane64(dk, ctz64(du)) : ~0ull;
+    dlast = rdlane64(dk, D - 1);
+  };
+  // ---- Truncate to B (beamSearch.h:157): the `excess` largest entries of (LDS beam, delta list) leave; both are sorted
+  auto truncate = [&]() {
+    int excess = M + D - B;
+    if (excess <= 0) return;
+    // the usual case in one step: everything that leaves is in the LDS beam (its entry M - excess is beyond the delta list's last)
+    const int q = M - excess;
+    if (WANN_LIKELY(q >= 1 && q - 1 >= tb) && (rdlane64(tv, q - tb) | 1ull) > (dlast | 1ull)) {
+      M = q;
+      mlk = rdlane64(tv, M - 1 - tb);
+      return;
+    }
+    for (; excess > 0; excess--) {
+      if (D > 0 && (M == 0 || (dlast | 1ull) > (mlk | 1ull))) {
+        if (lane == D - 1) dk = ~0ull;
+        D--;
+        if (dlast == dhead) dhead = ~0ull;  // (it was the only unvisited entry)
+        dlast = D ? rdlane64(dk, D - 1) : 0ull;
+      } else {
+        M--;
+        if (M == 0) mlk = 0;
+        else if (WANN_LIKELY(M - 1 >= tb)) mlk = rdlane64(tv, M - 1 - tb);
+        else load_tail();
+      }
+    }
+  };
+  auto window_lost = [&]() {  // after a truncation: the window may have lost entries
+    if (WANN_UNLIKELY(M < wbase + 64)) {
+      const int keep = M - wbase;
+      wum = keep <= 0 ? 0ull : (wum & ((((u64)1 << (keep - 1)) << 1) - 1));
+      if (!wum) pmk = ~0ull;
+      if (M - 1 < req_pos) {
+        forget_requests();
+        nx_node = -1;
+      }
+    }
+  };
+  // packets are requested for the next four unvisited entries of the window
+  auto request_packets = [&]() {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {  // (one per hop keeps the distance; two catch up after a restart)
+      if (r == 1 && WANN_LIKELY(nreq - rq_next >= 4)) break;
+      u64 cand = wum;
+      const int rel = req_pos - wbase;  // window bits <= rel have been requested
+      if (rel >= 63) cand = 0;
+      else if (rel >= 0) cand &= ~(((u64)2 << rel) - 1);
+      if (!cand) break;
+      const int j = ctz64(cand);
+      if (popc64(wum & (((u64)1 << j) - 1)) >= 4) break;
+      const int node = (int)((uint32_t)rdlane((int)(uint32_t)wv, j) >> 1);
+      if (lane == 0) {
+        vb->req[nreq & (kReqRing - 1)] = node;
+        vb->req_head = nreq + 1;
+      }
+      nreq++;
+      req_pos = wbase + j;
+    }
+  };
+  // the next hop's node, as far as one can tell now (a candidate of this hop may still come first): its packet and its probes
+  // are fetched while this hop's candidates are inserted.  The probes are issued after this hop's filter stores and seen-set
+  // updates (same wave, program order), so they see them.
+  auto fetch_next = [&]() {
+    if (box && wum && !((dhead | 1ull) < (pmk | 1ull)) && wbase + ctz64(wum) <= req_pos) {
+      const int nn = (int)((uint32_t)pmk >> 1);
+      if (read_packet(rq_next % kPkSlots, nn, nx_a, nx_loc, nx_dist, nx_mask, nx_flags)) {
+        nx_node = nn;
+        // (no lane-dependent branch around the loads: an unused slot's filter slot lies inside the table like any other,
+        // and its seen-set word is read at node 0)
+        nx_old = gtable[nx_loc & tmask];
+        nx_sw = __hip_atomic_load(gseen + ((nx_a < 0 ? 0 : nx_a) >> 5), __ATOMIC_RELAXED, kSeenScope);
+      }
+    }
+  };
+
+  unsigned long long tp = 0, acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define WANN_PHASE(i)                                       \
   do {                                                      \
     if (prof) {                                             \
@@ -1218,21 +1330,99 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     // at the join of ANY lane-dependent branch (`if (valid) store` next to `flag = ...` is enough), and one such value in
     // one exit test turns the whole loop into an exec-masked one with every scalar in vector registers.  A readfirstlane of
     // a value the compiler already knows to be uniform folds away.
-    M = uni(M);
-    D = uni(D);
-    wbase = uni(wbase);
-    tb = uni(tb);
-    nreq = uni(nreq);
-    rq_next = uni(rq_next);
-    req_pos = uni(req_pos);
-    nx_node = uni(nx_node);
-    nvis = uni(nvis);
-    wum = (u64)uni64((long long)wum);
-    pmk = (u64)uni64((long long)pmk);
-    dhead = (u64)uni64((long long)dhead);
-    dlast = (u64)uni64((long long)dlast);
-    mlk = (u64)uni64((long long)mlk);
-    cutoff = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cutoff)));
+#define WANN_UNIFORM_STATE()                                              \
+  do {                                                                    \
+    M = uni(M);                                                           \
+    D = uni(D);                                                           \
+    wbase = uni(wbase);                                                   \
+    tb = uni(tb);                                                         \
+    nreq = uni(nreq);                                                     \
+    rq_next = uni(rq_next);                                               \
+    req_pos = uni(req_pos);                                               \
+    nx_node = uni(nx_node);                                               \
+    nvis = uni(nvis);                                                     \
+    wum = (u64)uni64((long long)wum);                                     \
+    pmk = (u64)uni64((long long)pmk);                                     \
+    dhead = (u64)uni64((long long)dhead);                                 \
+    dlast = (u64)uni64((long long)dlast);                                 \
+    mlk = (u64)uni64((long long)mlk);                                     \
+    cutoff = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cutoff))); \
+  } while (0)
+    WANN_UNIFORM_STATE();
+
+    // ---- THE FAST PATH, a tight loop of its own: the hop whose node is the one the previous hop expected (the first unvisited
+    //      entry of the window, not of the delta list), with its packet and both probes fetched already, in a row without
+    //      shared filter slots.  Nine hops in ten of a long search.  Same steps, same order as the general hop below -- minus
+    //      every branch that hop needs for the rest, so that the compiler lays this one out straight and keeps its state in
+    //      registers (a lone wave pays ~7 cycles per instruction: instructions are what a hop costs).
+    while (WANN_LIKELY(box != nullptr && nx_node >= 0 && wum != 0 && nx_node == (int)((uint32_t)pmk >> 1) && !(uni(nx_flags) & 1) &&
+                       !((dhead | 1ull) < (pmk | 1ull)) && nvis < lim && !(check_abort && (nvis & 31) == 0))) {
+      const int i = ctz64(wum);
+      if (lane == 0) mb[wbase + i] = pmk | 1ull;
+      wum &= wum - 1;
+      const bool consumed = wbase + i <= req_pos;
+      nvis++;
+      st_nx += (lane == 0) ? 1 : 0;
+      st_pk += (lane == 0) ? 1 : 0;
+      const int a = nx_a;
+      const uint32_t loc = nx_loc, sw = nx_sw;
+      const int old = nx_old;
+      float dist = nx_dist;
+      const u64 pk_mask = nx_mask;
+      const bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+      if (consumed) rq_next++;
+      nx_node = -1;
+      WANN_PHASE(0);
+      if (prof) {  // (profile builds: how long the probes issued during the previous hop are still in flight)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WANN_PHASE(9);
+      }
+      if (WANN_UNLIKELY(popc64(wum) < 4 && wbase + 64 < M)) load_window(wum ? wbase + ctz64(wum) : wbase + 64);
+      else pmk = wum ? rdlane64(wv, ctz64(wum)) : ~0ull;
+      request_packets();
+      WANN_PHASE(2);
+      // lossy seen-filter (no shared slots in this row: the sequential rule is "old == id") + exact seen set
+      // (Measured, same box: the compiler issues the filter's store BEFORE it waits for the second probe, so that wait also
+      // covers the store's round trip -- the vector-memory counter retires in order -- and the phase takes 830 cycles; holding
+      // the store back behind the probes (an asm barrier) halves the phase and makes the whole search 5 % SLOWER: 9.66 vs
+      // 9.14 ms at beam 5 120.  Left as the compiler orders it.)
+      const int tagged = (int)(tag | (uint32_t)a);
+      const bool seen = valid && (old == tagged);
+      const bool kept = valid && !seen;  // what the reference scores
+      ncmp_v += kept ? 1 : 0;
+      const bool take = kept && !((sw >> (a & 31)) & 1u);  // what is computed
+      if (valid) gtable[loc] = tagged;
+      if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, kSeenScope);
+      WANN_PHASE(4);
+      fetch_next();
+      WANN_PHASE(5);
+      const bool need = take && !((pk_mask >> lane) & 1ull);
+      if (WANN_UNLIKELY(ballot64(need) != 0)) {
+        st_own += (lane == 0) ? 1 : 0;
+        L.cand_key[lane] = dk;
+        const float own = wave_distances_own<METRIC, true>(ix, a, need, L.qv, row_off);
+        dk = L.cand_key[lane];
+        if (need) dist = own;
+      }
+      const bool pass = take && (dist < cutoff);
+      const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
+      const u64 pmask = ballot64(pass);
+      WANN_PHASE(6);
+      if (pmask) {
+        if (WANN_UNLIKELY(D + popc64(pmask) > 64)) {
+          flush();
+          WANN_PHASE(10);
+        }
+        delta_insert(pmask, key, pass);
+        WANN_PHASE(7);
+        truncate();
+        window_lost();
+        set_cutoff();
+        WANN_PHASE(8);
+      }
+      WANN_UNIFORM_STATE();
+    }
+
     // ---- visit the closest unvisited entry of the beam (beamSearch.h:108-117): the closer of the first unvisited
     //      entry of the LDS beam and the first unvisited entry of the delta list
     if ((pmk == ~0ull && dhead == ~0ull) || nvis >= lim) break;
@@ -1244,7 +1434,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     const bool from_delta = (dhead | 1ull) < (pmk | 1ull);
     int cur;
     bool consumed = false;  // the visited entry had a packet requested
-    if (WANN_UNLIKELY(from_delta)) {
+    if (from_delta) {
       cur = (int)((uint32_t)dhead >> 1);
       if (dk == dhead) dk |= 1ull;  // (keys are unique)
       const u64 du = ballot64(lane < D && !(dk & 1ull));
@@ -1270,7 +1460,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     float pk_dist = 0.f;
     u64 pk_mask = 0;
     bool valid;
-    if (WANN_LIKELY(cur == nx_node && !from_delta)) {
+    if (cur == nx_node && !from_delta) {
       st_nx += (lane == 0) ? 1 : 0;
       a = nx_a;
       loc = nx_loc;
@@ -1288,7 +1478,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
       if (valid) {
         old = gtable[loc];
-        sw = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sw = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, kSeenScope);
       }
     }
     if (consumed) rq_next++;
@@ -1296,37 +1486,18 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     st_pk += (lane == 0 && (flags & 2)) ? 1 : 0;  // (lane-dependent on purpose: a statistic must not cost a scalar register)
     WANN_PHASE(1);  // row, filter slots, probes
 
-    // ---- the window follows the first unvisited entry; packets are requested for the next four unvisited entries
+    // ---- the window follows the first unvisited entry
     if (!from_delta) {
       if (WANN_UNLIKELY(popc64(wum) < 4 && wbase + 64 < M)) load_window(wum ? wbase + ctz64(wum) : wbase + 64);
       else pmk = wum ? rdlane64(wv, ctz64(wum)) : ~0ull;
     }
-    if (box) {
-#pragma unroll
-      for (int r = 0; r < 2; r++) {  // (one per hop keeps the distance; two catch up after a restart)
-        if (r == 1 && WANN_LIKELY(nreq - rq_next >= 4)) break;
-        u64 cand = wum;
-        const int rel = req_pos - wbase;  // window bits <= rel have been requested
-        if (rel >= 63) cand = 0;
-        else if (rel >= 0) cand &= ~(((u64)2 << rel) - 1);
-        if (!cand) break;
-        const int j = ctz64(cand);
-        if (popc64(wum & (((u64)1 << j) - 1)) >= 4) break;
-        const int node = (int)((uint32_t)rdlane((int)(uint32_t)wv, j) >> 1);
-        if (lane == 0) {
-          vb->req[nreq & (kReqRing - 1)] = node;
-          vb->req_head = nreq + 1;
-        }
-        nreq++;
-        req_pos = wbase + j;
-      }
-    }
+    if (box) request_packets();
     WANN_PHASE(2);  // next unvisited entry + packet requests
 
     // ---- lossy seen-filter (sequential semantics, beamSearch.h:68-73,126-131) + exact seen set
     const int tagged = (int)(tag | (uint32_t)a);
     bool clash;
-    if (WANN_LIKELY(flags & 2)) clash = (flags & 1) != 0;  // (the helper's exact test)
+    if (flags & 2) clash = (flags & 1) != 0;  // (the helper's exact test)
     else {
       // exact test "two valid lanes of the row share a filter slot": every lane tags its slot of a small LDS hash with
       // its lane number; a lane that lost its slot compares filter slots with the winner, and the few lanes whose
@@ -1380,22 +1551,10 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     ncmp_v += kept ? 1 : 0;
     const bool fresh = kept && !((sw >> (a & 31)) & 1u);
     const bool take = twice ? kept : fresh;  // what is computed
-    if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, kSeenScope);
     WANN_PHASE(4);  // seen-filter
 
-    // ---- the next hop's node, as far as one can tell now (a candidate of this hop may still come first): its packet and
-    //      its probes are fetched while this hop's candidates are inserted.  The probes are issued after this hop's filter
-    //      stores and seen-set updates (same wave, program order), so they see them.
-    if (box && wum && !((dhead | 1ull) < (pmk | 1ull)) && wbase + ctz64(wum) <= req_pos) {
-      const int nn = (int)((uint32_t)pmk >> 1);
-      if (read_packet(rq_next % kPkSlots, nn, nx_a, nx_loc, nx_dist, nx_mask, nx_flags)) {
-        nx_node = nn;
-        // (no lane-dependent branch around the loads: an unused slot's filter slot lies inside the table like any other,
-        // and its seen-set word is read at node 0)
-        nx_old = gtable[nx_loc & tmask];
-        nx_sw = __hip_atomic_load(gseen + ((nx_a < 0 ? 0 : nx_a) >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    fetch_next();
     WANN_PHASE(5);  // next hop's packet and probes
 
     if (WANN_UNLIKELY(twice)) flush();  // the exact multiset union below works on the whole beam
@@ -1403,7 +1562,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     //      neighbour the helper took for scored already) is computed here
     float dist = pk_dist;
     const bool need = take && !((pk_mask >> lane) & 1ull);
-    if (WANN_UNLIKELY(ballot64(need) != 0)) {
+    if (ballot64(need) != 0) {
       st_own += (lane == 0) ? 1 : 0;
       // (the delta list waits in the merge scratch meanwhile: the scoring routine keeps a whole row per lane pair in
       // flight and needs every register)
@@ -1424,46 +1583,19 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       M = wave_merge(mb, M, B, pass, key, L.cand_key, &p0);
       resync(pm < p0 ? pm : p0);
     } else if (pmask) {
-      if (WANN_UNLIKELY(D + popc64(pmask) > 64)) flush();
-      for (u64 mm = pmask; mm; mm &= mm - 1) {  // into the delta list: vector operations only after the broadcast
-        const u64 k = rdlane64(key, ctz64(mm));
-        const bool lt = (dk | 1ull) < (k | 1ull);  // (lanes >= D hold ~0: never)
-        const int f = lt ? 1 : 0;
-        const int fprev = __builtin_amdgcn_update_dpp(1, f, 0x138, 0xf, 0xf, false);  // lane - 1's; lane 0: 1
-        const u64 up = wave_shr1(dk);
-        dk = lt ? dk : (fprev ? k : up);
-        D++;
-        if ((k | 1ull) < (dhead | 1ull)) dhead = k;
-        if ((k | 1ull) > (dlast | 1ull)) dlast = k;
+      if (WANN_UNLIKELY(D + popc64(pmask) > 64)) {
+        flush();
+        WANN_PHASE(10);
       }
+      delta_insert(pmask, key, pass);
       WANN_PHASE(7);  // into the delta list
-      // truncate to B: the largest entry of (LDS beam, delta list) leaves, `excess` times; both are sorted
-      for (int excess = M + D - B; excess > 0; excess--) {
-        if (D > 0 && (M == 0 || (dlast | 1ull) > (mlk | 1ull))) {
-          if (lane == D - 1) dk = ~0ull;
-          D--;
-          if (dlast == dhead) dhead = ~0ull;  // (it was the only unvisited entry)
-          dlast = D ? rdlane64(dk, D - 1) : 0ull;
-        } else {
-          M--;
-          if (M == 0) mlk = 0;
-          else if (WANN_LIKELY(M - 1 >= tb)) mlk = rdlane64(tv, M - 1 - tb);
-          else load_tail();
-        }
-      }
-      if (WANN_UNLIKELY(M < wbase + 64)) {  // the window lost entries
-        const int keep = M - wbase;
-        wum = keep <= 0 ? 0ull : (wum & ((((u64)1 << (keep - 1)) << 1) - 1));
-        if (!wum) pmk = ~0ull;
-        if (M - 1 < req_pos) {
-          forget_requests();
-          nx_node = -1;
-        }
-      }
+      truncate();
+      window_lost();
       set_cutoff();
     }
     WANN_PHASE(8);  // truncation
   }
+#undef WANN_UNIFORM_STATE
 #undef WANN_PHASE
   if (box && lane == 0) vb->gen = 0;  // (the next search picks the next generation)
   if (D) {
@@ -1472,7 +1604,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   }
   for (int o = 32; o; o >>= 1) ncmp_v += __shfl_xor(ncmp_v, o);
   if (prof && lane == 0)
-    for (int i = 0; i < 10; i++) atomicAdd(&prof[i], acc[i]);
+    for (int i = 0; i < 12; i++) atomicAdd(&prof[i], acc[i]);
   if (ctr && lane == 0) {
     atomicAdd(&ctr->big_searches, 1ull);
     atomicAdd(&ctr->big_hops, (unsigned long long)nvis);

@@ -623,6 +623,72 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
 
 
 // --------------------------------------------------------------------------------------------
+// A sorted run of D <= 64 NEW keys (lane j holds the j-th smallest; none is in the beam yet) into the sorted LDS beam
+// mb[0..M): the one-wave kernel's delta list going into a beam of thousands, every fourteen hops of a long search.  Worked
+// in DESTINATION space, where the run's slots are distinct positions (slot of key j = its lower bound + j): a bit per
+// position in `flagw` (LDS words, one ds_or for the whole run), and for a chunk of 64 destinations the number of run slots
+// below destination y is a running count plus a v_mbcnt of the chunk's 64 flag bits -- no loop over the keys that land in
+// a chunk, no rank arithmetic: twenty instructions per chunk where the general union (wave_merge) spends forty-five.
+// Chunks go top down; a chunk's sources lie at or below its destinations and above nothing that has been written yet, and
+// LDS operations of a wave execute in order, so reads and writes of neighbouring chunks need no waits between them.
+// Returns M + D; *first_pos = position of the first key of the run.  flagw must hold (M + D + 127) / 32 words.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_merge_run(u64 *mb, int M, u64 dk, int D, int32_t *flagw, int *first_pos) {
+  const int lane = lane_id();
+  const u64 k1 = dk | 1ull;  // (lanes >= D hold ~0: their lower bound is M)
+  int lo = 0, hi = M;
+  const int iters = 32 - __builtin_clz(M | 1) + 1;
+  for (int it = 0; it < iters; it++) {
+    const int mid = (lo + hi) >> 1;
+    const u64 bv = mb[mid < M ? mid : (M > 0 ? M - 1 : 0)] | 1ull;
+    if (lo < hi) {
+      if (bv < k1) lo = mid + 1;
+      else hi = mid;
+    }
+  }
+  const int posd = lo + lane;  // destination of this lane's key
+  const int newM = M + D;
+  const int p0 = rdlane(lo, 0);
+  const int base_lo = p0 & ~63;
+  for (int w = (base_lo >> 5) + lane; w <= ((newM - 1) >> 5) + 1; w += 64) flagw[w] = 0;
+  WAVE_SYNC();
+  if (lane < D) __hip_atomic_fetch_or(&flagw[posd >> 5], (int32_t)(1u << (posd & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  WAVE_SYNC();
+  int H = D;  // run slots below the end of the chunk being worked
+  constexpr int NCH = 4;
+  for (int top = (newM - 1) & ~63; top >= base_lo; top -= 64 * NCH) {
+    u64 cm[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {  // (no branches around the reads: a chunk below the first moved one reads that one's flags and drops them)
+      const int base = top - 64 * j;
+      cm[j] = *reinterpret_cast<const u64 *>(flagw + ((base >= base_lo ? base : base_lo) >> 5));  // (the same word pair in every lane)
+    }
+    u64 ev[NCH];
+    int dst[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      const int base = top - 64 * j;
+      u64 c = (u64)uni64((long long)cm[j]);
+      if (base < base_lo) c = 0ull;
+      const int H0 = H - popc64(c);
+      H = H0;
+      const int y = base + lane;
+      const int h = H0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(c >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c, 0u));
+      const bool mv = y < newM && y >= p0 && !((c >> lane) & 1ull);  // (y >= p0 >= base_lo: never in a chunk below the first)
+      dst[j] = mv ? y : -1;
+      ev[j] = mb[mv ? y - h : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; j++)
+      if (dst[j] >= 0) mb[dst[j]] = ev[j];
+  }
+  if (lane < D) mb[posd] = dk;
+  WAVE_SYNC();
+  *first_pos = p0;
+  return newM;
+}
+
+// --------------------------------------------------------------------------------------------
 // beam-search core: one wavefront runs one search (beamSearch.h:51-184) over partition `part`
 // for the query staged (zero padded) in L.qv.  The beam lives in LDS (BEAM_LDS) or in gbeam, the
 // seen-filter in LDS (TABLE_LDS) or in gtable.  COLLECT appends every visited (dist,id) key to
@@ -1204,11 +1270,14 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     pflags = rf | 2;    // bit 1: the row's slot-sharing test is known (bit 0)
     return true;
   };
+  // (the flag words of wave_merge_run live in the clash test's scratch beside the beam -- the two are never in use together)
+  const bool run_merge = (int)mini_mask + 1 >= ((B + 64 + 127) >> 5) + 2 && mini != reinterpret_cast<int32_t *>(L.cand_key);
   auto flush = [&]() {  // merge the delta list into the LDS beam
     if (D == 0) return;
     const int pm = wum ? wbase + ctz64(wum) : M;
     int p0;
-    M = wave_merge<u64 *, false, true>(mb, M, B, lane < D, dk, L.cand_key, &p0);
+    if (WANN_LIKELY(run_merge)) M = wave_merge_run(mb, M, dk, D, mini, &p0);
+    else M = wave_merge<u64 *, false, true>(mb, M, B, lane < D, dk, L.cand_key, &p0);
     D = 0;
     dk = ~0ull;
     resync(pm < p0 ? pm : p0);
@@ -1600,7 +1669,8 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   if (box && lane == 0) vb->gen = 0;  // (the next search picks the next generation)
   if (D) {
     int p0;
-    M = wave_merge<u64 *, false, true>(mb, M, B, lane < D, dk, L.cand_key, &p0);
+    if (run_merge) M = wave_merge_run(mb, M, dk, D, mini, &p0);
+    else M = wave_merge<u64 *, false, true>(mb, M, B, lane < D, dk, L.cand_key, &p0);
   }
   for (int o = 32; o; o >>= 1) ncmp_v += __shfl_xor(ncmp_v, o);
   if (prof && lane == 0)

@@ -500,6 +500,8 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
   // (look-ahead slot of a task: none.  A resolved parent is never reset by a wave before the one-wave kernel reads it.)
   if (spec) HIP_CHECK(hipMemsetAsync(W.sub_cmps.p, 0xFF, ((size_t)nq * maxt) * sizeof(long long), st));
+  // (lowest level of a speculating task that has found k entries so far: none -- higher levels become moot, k_search)
+  if (spec) HIP_CHECK(hipMemsetAsync(W.sub_hops.p, 0x7F, ((size_t)nq * maxt) * sizeof(long long), st));
   // (a sub-task slot's count is -1 until its search has finished: what the pollers' scan goes by)
   if (spec) HIP_CHECK(hipMemsetAsync(W.out_cnt.p + (size_t)nq * maxt, 0xFF, (size_t)sub_slots * sizeof(int32_t), st));
   I.last = wann_counters{};

@@ -1133,8 +1133,10 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
                                                      uint32_t mini_mask, int &m_out, long long &nvis_out,
                                                      long long &ncmp_out, unsigned long long *prof = nullptr,
                                                      ScoreBox *box = nullptr, int part_index = 0,
-                                                     const int32_t *abort_flag = nullptr, Counters *ctr = nullptr) {
+                                                     const int32_t *abort_flag = nullptr, Counters *ctr = nullptr,
+                                                     const long long *moot_word = nullptr, int my_level = 0) {
   // abort_flag: a look-ahead search (k_search) that its chain has withdrawn (*abort_flag == 2) stops at the next check
+  // moot_word: a speculated level stops when a LOWER level of its task has found k entries (*moot_word < my_level)
   //
   // A search wave runs alone on its SIMD, so every dependent instruction costs its full latency and every trip between
   // the vector and the scalar side (ballot -> branch -> readlane ...) a few dozen cycles.  The hop below therefore keeps
@@ -1146,7 +1148,8 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   // Every wave-uniform argument into scalar registers, explicitly: ONE value the compiler can not prove uniform (a pointer
   // selected by a loaded flag, say) in ONE exit test makes the whole hop loop "divergent" -- and then every loop-carried
   // scalar (list sizes, window mask, cutoff ...) lives in vector registers under exec masks.
-  const bool check_abort = uni((int)(abort_flag != nullptr)) != 0;
+  const bool check_abort = uni((int)(abort_flag != nullptr || moot_word != nullptr)) != 0;
+  my_level = uni(my_level);
   tag = (uint32_t)uni((int)tag);
   B = uni(B);
   bits = uni(bits);
@@ -1497,7 +1500,10 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     if ((pmk == ~0ull && dhead == ~0ull) || nvis >= lim) break;
     if (WANN_UNLIKELY(check_abort && (nvis & 31) == 0)) {
       int ab = 0;
-      if (lane == 0) ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) {
+        if (abort_flag) ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (moot_word && __hip_atomic_load(moot_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < my_level) ab = 2;
+      }
       if (uni(ab) == 2) break;
     }
     const bool from_delta = (dhead | 1ull) < (pmk | 1ull);

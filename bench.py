@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--fractions", default=None, help="'all' = also sweep 2^-16..2^0 (N=1; default for sift), 'headline' = skip, or a list of exponents '-9,-6'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
+    ap.add_argument("--rotate", type=int, default=4, help="distinct query / window draws the timed steps rotate through (1 = the same batch every step)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
     ap.add_argument("--configs", default=None, help="N=1: the other BASELINE.json configurations as extra legs of the line: 'all' = glove "
                     "(configs[2]), deep (configs[3] on this one GPU), adverse (configs[4]); 'none'; or a comma list")
@@ -242,13 +243,15 @@ def main():
 
     n, d = args.n, args.dim
     draws = world if args.scaling == "weak" else 1
+    rot = max(1, args.rotate)
     gnq = args.nq * draws                      # the job's batch
     lo, hi = shard_bounds(gnq, world, rank)    # this rank's shard (global query numbers)
     nq = hi - lo
     R, L, alpha, cutoff, split = wl["R"], wl["L"], wl["alpha"], wl["cutoff"], wl["split"]
     method = wl["method"]
     t0 = time.time()
-    X, Qg, labels = wl["make"](n, d, args.nq, draws)
+    X, Qall, labels = wl["make"](n, d, args.nq, draws * rot)   # `rot` batches: the timed steps rotate through them
+    Qg = Qall[:gnq]
     log(f"data n={n} d={d} batch={gnq} ({args.scaling} scaling, {world} rank(s)) in {time.time() - t0:.1f}s; host cpus={ncpu}")
 
     cache = os.path.join(args.cache, f"{wl['cache']}_n{n}_d{d}_R{R}_L{L}_c{cutoff}_s{split}") + "/"
@@ -282,9 +285,9 @@ def main():
     def qparams(mod, beam, mult):
         return mod.QueryParams(K, beam, 1.35, 10_000_000, 10_000, mult, 10000, None, False)
 
-    def global_windows(p, seed):
-        """windows of the whole batch: draw r uses seed + r (a weak-scaling rank's shard is one draw)"""
-        return np.concatenate([make_windows(ls, args.nq, p, seed + r) for r in range(draws)])
+    def global_windows(p, seed, rotation=0):
+        """windows of the whole batch: draw r uses seed + r (a weak-scaling rank's shard is one draw); rotation j > 0 = another draw"""
+        return np.concatenate([make_windows(ls, args.nq, p, seed + r + 7919 * rotation) for r in range(draws)])
 
     def run(Wt, beam, mult):
         """this rank's shard through the device-pointer C-ABI entry point"""
@@ -311,7 +314,8 @@ def main():
                 wall = time.perf_counter() - t
                 c = index.counters()
                 rec = recall_of(torch, gt, gcnt, ids_t)
-                rows.append(dict(beam=beam, mult=mult, recall=rec, wall_ms=wall * 1e3, device_ms=c["device_ms"]))
+                rows.append(dict(beam=beam, mult=mult, recall=rec, wall_ms=wall * 1e3, device_ms=c["device_ms"], kernel_ms=c["search_kernel_ms"],
+                                 alg_bytes=4 * (R + 1) * c["hops"] + 4 * d * (c["dist_cmps"] + c["brute_rows"]) + 4 * c["label_reads"]))
                 if rec > 0.95 and (best_ok is None or wall * 1e3 < best_ok):
                     best_ok = wall * 1e3
                 scans_only = c["beam_searches"] == 0 and c["brute_rows"] > 0
@@ -355,8 +359,13 @@ def main():
         dist.broadcast(bm, 0)
         beam, mult = int(bm[0]), int(bm[1])
 
-    agg = dict(beam_searches=0, hops=0, dist_cmps=0, label_reads=0, brute_rows=0, search_kernel_ms=0.0, device_ms=0.0, rounds=0)
+    agg = dict(beam_searches=0, hops=0, dist_cmps=0, label_reads=0, brute_rows=0, search_kernel_ms=0.0, device_ms=0.0, rounds=0,
+               poll_timeouts=0, recovered_continuations=0)
     qp_run = qparams(wa, beam, mult)
+    # the batches the timed steps rotate through: rotation 0 is the batch the sweep ran on; the others are fresh query AND window
+    # draws (a step that replays one batch finds the upper tree levels' nodes cache-warm from the step before)
+    rot_q = [Qgt] + [torch.from_numpy(Qall[j * gnq:(j + 1) * gnq]).to(dev) for j in range(1, rot)]
+    rot_w = [Wgt] + [torch.from_numpy(global_windows(args.fraction, 1000, j)).to(dev) for j in range(1, rot)]
 
     def search_fn(q, r, base, out_ids=None, out_dists=None):
         """local search of one shard: (nq_shard, d) / (nq_shard, 2) device tensors, global number of its first query; the rows
@@ -370,30 +379,41 @@ def main():
             agg[kk] += c[kk]
         return oi, od
 
-    def step():
+    def step(j=0):
         # query shards -> HIP batch_search on this rank's GPU -> ONE all-gather of the per-shard top-k over RCCL/xGMI
-        return sharded_batch_search(search_fn, Qgt, Wgt, K)
+        return sharded_batch_search(search_fn, rot_q[j], rot_w[j], K)
 
-    for _ in range(args.warmup):
-        step()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    for kk in agg:
-        agg[kk] = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        all_ids, all_d = step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    def timed(rotating):
+        """exactly args.steps steps between barrier + synchronize on both sides; MAX over the ranks"""
+        for i in range(args.warmup):
+            step(i % rot if rotating else 0)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for kk in agg:
+            agg[kk] = 0
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i % rot if rotating else 0)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            te = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el, out, dict(agg)
+
+    # the same batch every step (rounds 1-3 timed this) -- reported beside `value`; then THE timed region: rotating batches
+    same_elapsed, _, same_agg = timed(False) if rot > 1 else (None, None, None)
+    elapsed, _, _ = timed(True)
     ms_per_step = elapsed / args.steps * 1e3
     qps = gnq * args.steps / elapsed
+    timed_agg = dict(agg)
+    all_ids, all_d = step(0)  # rows of rotation 0 for the recall / reference comparison below
+    for kk in agg:
+        agg[kk] = timed_agg[kk]
     # recall of the gathered result rows of this rank's shard (every rank holds every row), averaged over the ranks
     gt_l, gcnt_l = ground_truth(torch, Xt, x2, labt, Qt, Wt, K)
     final_recall = recall_of(torch, gt_l, gcnt_l, all_ids[lo:hi])
@@ -448,6 +468,10 @@ def main():
                                f"window 2^{args.fraction}, {gnq} queries per step ({nq} on rank 0), k={K}",
                    "beam": beam, "final_beam_multiply": mult, "recall_at_10": round(final_recall, 4),
                    "build_s": round(build_s, 1), "index_gib": round(index.device_bytes() / 2**30, 2),
+                   "rotating_batches": rot,
+                   "same_batch_qps": None if same_elapsed is None else round(gnq * args.steps / same_elapsed, 1),
+                   "same_batch_kernel_ms_per_step": None if same_agg is None else round(same_agg["search_kernel_ms"] / args.steps, 4),
+                   "poll_timeouts": int(agg["poll_timeouts"]), "recovered_continuations": int(agg["recovered_continuations"]),
                    "host_buffer_call_ms": None if host_ms is None else round(host_ms, 3),
                    "host_buffer_qps": None if host_ms is None else round(nq / host_ms * 1e3, 1),
                    "parallelism": (f"replicated index x{world}, contiguous query shards, one RCCL all-gather of the per-shard top-k per step"
@@ -489,7 +513,11 @@ def main():
             if b is None:  # no setting of the sweep reaches recall 0.95 here (the reference does not either: same rows)
                 b = max(rws, key=lambda r: r["recall"])
             per[f"2^{p}"] = dict(qps=round(nq / b["wall_ms"] * 1e3, 1), recall=round(b["recall"], 4), beam=b["beam"], mult=b["mult"],
-                                 device_ms=round(b["device_ms"], 3), meets_recall=meets, settings_swept=len(rws))
+                                 device_ms=round(b["device_ms"], 3), meets_recall=meets, settings_swept=len(rws),
+                                 # algorithmic bytes of the call (graph rows + scored vectors, exact scans included)
+                                 # over the WHOLE call's device time, against the 8 TB/s HBM peak
+                                 algorithmic_gb=round(b["alg_bytes"] / 1e9, 3),
+                                 roofline_frac=round(b["alg_bytes"] / (b["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b["device_ms"] > 0 else None)
             log(f"  2^{p}: {per[f'2^{p}']}")
             if want_ref:
                 run(Wpt[lo:hi], b["beam"], b["mult"])

@@ -110,6 +110,15 @@ print(json.dumps(dict(workload=f"adversarial 100x10000 d={d} MIPS, 9900 queries,
                       scan_ms=out["scan"]["ms"], scan_qps=out["scan"]["qps"], mfma_equals_scan=bool(same),
                       gemm_queries=out["mfma"]["counters"]["gemm_queries"], gemm_unproven=out["mfma"]["counters"]["gemm_unproven"], gemm_rescued=out["mfma"]["counters"]["gemm_rescued"], device_ms=round(out["mfma"]["counters"]["device_ms"], 3), gemm_tflops_incl_select=round(flops / out["mfma"]["ms"] / 1e9, 2),
                       cpu_reference=cpu.get("native"),
+                      # the MFMA leg against its roofline: a window group reads each of its point rows ONCE (padded row of
+                      # 16 * ceil(d / 16) floats; 100 groups x 10 000 rows here), so the floor is the HBM's, not the matrix
+                      # pipes' (DESIGN.md 3.3b "Round 3"); `achieved` is over the WHOLE call's device time (ten small launches) --
+                      # k_gemm_scores alone: profiles/*_prefilter_rocprofv3_kernel_stats.csv
+                      roofline=dict(bound="hbm", kernel="k_gemm_scores (whole call: route + grouping + GEMM + select / re-rank + finalize)",
+                                    achieved=round(100 * per * (16 * ((d + 15) // 16)) * 4 / (out["mfma"]["counters"]["device_ms"] * 1e-3) / 1e9, 1),
+                                    peak=8000.0, unit="GB/s",
+                                    frac=round(100 * per * (16 * ((d + 15) // 16)) * 4 / (out["mfma"]["counters"]["device_ms"] * 1e-3) / 1e9 / 8000.0, 4),
+                                    algorithmic_gb=round(100 * per * (16 * ((d + 15) // 16)) * 4 / 1e9, 4), traffic=None),
                       synthetic_2pow_minus12=dict(workload=f"same points, synthetic windows of {w} points (2^-12), exact scan (k_brute)", ms=out["p12"]["ms"], qps=out["p12"]["qps"],
                                                   device_ms=round(p12_dev_ms, 4), brute_rows=int(out["p12"]["counters"]["brute_rows"]),
                                                   algorithmic_gb=round(scan_bytes / 1e9, 4),

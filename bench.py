@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--fractions", default=None, help="'all' = also sweep 2^-16..2^0 (N=1; default for sift), 'headline' = skip, or a list of exponents '-9,-6'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
+    ap.add_argument("--pipeline", type=int, default=2, help="N = 1: also time the rotating batches through the ASYNCHRONOUS call, this many in flight "
+                    "(wann_batch_search_device_async; reported as config.pipelined_*, never as `value`); 0 / 1 = skip")
     ap.add_argument("--rotate", type=int, default=4, help="distinct query / window draws the timed steps rotate through (1 = the same batch every step)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
     ap.add_argument("--configs", default=None, help="N=1: the other BASELINE.json configurations as extra legs of the line: 'all' = glove "
@@ -426,6 +428,39 @@ def main():
         mx = sums[5:].clone()
         dist.all_reduce(sums)                         # work counters: summed over the ranks
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)     # kernel time: the slowest rank's
+    # the asynchronous call (two batches in flight: batch i + 1 is routed and ramps up under batch i's tail) over the same rotating
+    # batches -- beside `value` (the reference's protocol is one blocking call per batch), never as `value`
+    pipe = None
+    if rank == 0 and world == 1 and args.pipeline >= 2:
+        depth = min(args.pipeline, 2)
+        pouts = [(torch.empty((nq, K), dtype=torch.int32, device=dev), torch.empty((nq, K), dtype=torch.float32, device=dev)) for _ in range(depth + 1)]
+
+        def pipelined(nsteps):
+            tickets, ctrs = [], []
+            for i in range(nsteps):
+                oi, od = pouts[i % len(pouts)]
+                tickets.append(index.batch_search_device_async(rot_q[i % rot].data_ptr(), rot_w[i % rot].data_ptr(), nq, lo, method, qp_run,
+                                                               oi.data_ptr(), od.data_ptr(), 0))
+                if i >= depth - 1 and i - (depth - 1) >= 0 and len(tickets) > depth - 1:
+                    ctrs.append(index.wait(tickets[i - (depth - 1)]))
+            for t in tickets[len(ctrs):]:
+                ctrs.append(index.wait(t))
+            return ctrs
+        torch.cuda.synchronize()
+        pipelined(max(2, args.warmup))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pc = pipelined(args.steps)
+        torch.cuda.synchronize()
+        pel = time.perf_counter() - t1
+        p_bytes = sum(4 * (R + 1) * c["hops"] + d * 4 * c["dist_cmps"] + 4 * c["label_reads"] for c in pc)
+        # rows of one more rotation-0 batch through the asynchronous call against the blocking call's
+        index.wait(index.batch_search_device_async(rot_q[0].data_ptr(), rot_w[0].data_ptr(), nq, lo, method, qp_run, pouts[0][0].data_ptr(), pouts[0][1].data_ptr(), 0))
+        same = bool((pouts[0][0] == all_ids[lo:hi]).all().item()) and bool((pouts[0][1] == all_d[lo:hi]).all().item())
+        pipe = dict(in_flight=depth, qps=round(nq * args.steps / pel, 1), ms_per_step=round(pel / args.steps * 1e3, 4),
+                    hbm_frac_of_wall=round(p_bytes / pel / 1e9 / HBM_PEAK_GBS, 4), rows_equal_blocking_call=same)
+        log(f"pipelined ({depth} in flight): {pipe}")
+
     # the reference's own boundary (numpy in, numpy out): the same batch through the host-buffer entry point,
     # PCIe copies included -- reported beside `value`, never as `value`
     host_ms = None
@@ -468,7 +503,7 @@ def main():
                                f"window 2^{args.fraction}, {gnq} queries per step ({nq} on rank 0), k={K}",
                    "beam": beam, "final_beam_multiply": mult, "recall_at_10": round(final_recall, 4),
                    "build_s": round(build_s, 1), "index_gib": round(index.device_bytes() / 2**30, 2),
-                   "rotating_batches": rot,
+                   "rotating_batches": rot, "pipelined": pipe,
                    "same_batch_qps": None if same_elapsed is None else round(gnq * args.steps / same_elapsed, 1),
                    "same_batch_kernel_ms_per_step": None if same_agg is None else round(same_agg["search_kernel_ms"] / args.steps, 4),
                    "poll_timeouts": int(agg["poll_timeouts"]), "recovered_continuations": int(agg["recovered_continuations"]),

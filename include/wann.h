@@ -17,6 +17,7 @@
  *       src/range_filter_tree.h:62-96, src/super_optimized_postfilter_tree.h:60-87,
  *       src/postfilter_vamana.h:191-219, src/prefiltering.h:124-146
  *   wann_batch_search_device the same call with queries / ranges / outputs already resident in HBM
+ *   wann_batch_search_device_async / wann_wait   that call without blocking: two batches in flight (src/range_filter_tree.h:62-96)
  *   wann_query_params        QueryParams   ParlayANN/algorithms/utils/types.h:115-140, python_bindings.cpp:204-209
  *   wann_build_params        BuildParams   ParlayANN/algorithms/utils/types.h:77-112,  python_bindings.cpp:211-213
  *
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WANN_ABI_VERSION 3
+#define WANN_ABI_VERSION 4
 #define WANN_MAX_DEGREE 64
 
 enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP = 3, WANN_ERR_IO = 4,
@@ -142,6 +143,19 @@ int wann_batch_search_device(wann_index *index, const void *d_queries, const flo
                              int64_t nq, int64_t query_id_base, const char *method,
                              const wann_query_params *qp, uint32_t *d_ids, float *d_dists,
                              void *hip_stream);
+
+/* Asynchronous form of wann_batch_search_device (ABI 4).  The reference's call is blocking (src/range_filter_tree.h:62-96: it
+ * returns when every query is answered) and so are the two calls above; a serving loop that answers batch after batch leaves
+ * the GPU to the tail of one batch and the ramp-up of the next about a fifth of the time at 10 000 queries per batch.  This call
+ * returns at once with a ticket: the batch runs on one of two LANES of the index (a lane = its own per-batch workspace, streams
+ * and host worker thread), ordered after the work the caller has queued on `after_stream` so far (its inputs; NULL = the HIP
+ * default stream), and concurrently with the other lane's batch.  Same rows as the blocking call.  The output buffers belong
+ * to the call until wann_wait(ticket) has returned; wait for ticket t before submitting ticket t + 2 (its lane is reused).
+ * wann_wait returns the batch's status (message in wann_last_error) and, if `counters` is not NULL, its work counters. */
+int wann_batch_search_device_async(wann_index *index, const void *d_queries, const float *d_ranges, int64_t nq,
+                                   int64_t query_id_base, const char *method, const wann_query_params *qp, uint32_t *d_ids,
+                                   float *d_dists, void *after_stream, int64_t *ticket);
+int wann_wait(wann_index *index, int64_t ticket, wann_counters *counters);
 
 int wann_get_counters(const wann_index *index, wann_counters *out);
 

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <unistd.h>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -167,10 +168,14 @@ struct wann_index {
   // every WANN_* switch, read when the index is created (wann_tuning.h); run_batch never reads the environment
   Tuning tune;
   std::mutex mu;
-  ~wann_index() {
-    if (own_stream) (void)hipStreamDestroy(own_stream);
-    if (side_stream) (void)hipStreamDestroy(side_stream);
-  }
+  std::mutex dense_mu;  // the dense prefilter path's buffers and counters belong to the index: one batch at a time uses them
+  // wann_batch_search_device_async: further LANES -- a lane is everything one batch in flight needs (workspace, streams, a
+  // worker thread); the blocking calls use the members above
+  struct AsyncLane;
+  std::vector<std::unique_ptr<AsyncLane>> lanes;
+  std::mutex lanes_mu;
+  int64_t next_ticket = 0;
+  ~wann_index();
 };
 
 namespace {
@@ -398,8 +403,7 @@ int method_code(const char *m) {
 // every query whose top-k cannot be proven from the MFMA scores) goes through the exact scan kernel.  Grouping,
 // tile planning and the hand-over to the exact scan all happen on the device: the host enqueues six launches and
 // never waits.
-void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, hipStream_t st) {
-  Workspace &W = I.ws;
+void dense_prefilter(wann_index &I, Workspace &W, const float *d_queries, int64_t nq, int k, hipStream_t st) {
   if (k > kSelect / 2 || I.view.stride > 512 || (I.view.stride & 15)) return;  // (rows of up to 512 floats: RedCaps)
   if (!I.have_norms) {
     I.d_pnorm2.ensure((size_t)I.view.n);
@@ -477,14 +481,16 @@ void dense_prefilter(wann_index &I, const float *d_queries, int64_t nq, int k, h
 #endif
 }
 
-void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int64_t nq, int64_t qid_base,
-               const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st) {
+// W / side / last: the lane of this batch (the index's own members for the blocking calls, an AsyncLane's for the asynchronous one)
+void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &last, const float *d_queries, const float *d_ranges, int64_t nq,
+               int64_t qid_base, const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st) {
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
   // the brute-force classes ignore the beam (the reference driver passes beam_size = 0 there, run_our_method.py:256)
   if (qp.beam_width <= 0 && I.host().vamana_leaves) throw std::runtime_error("beam_width must be positive");
   if (qp.postfiltering_max_beam > (1 << 20)) throw std::runtime_error("postfiltering_max_beam too large");
   HIP_CHECK(hipSetDevice(I.device));
-  Workspace &W = I.ws;
+  std::unique_lock<std::mutex> dense_lock(I.dense_mu, std::defer_lock);
+  if (I.host().spec.kind == WANN_KIND_PREFILTER) dense_lock.lock();
   const int k = (int)qp.k;
   const int mcode = method_code(method);
   const bool tree = I.host().spec.kind == WANN_KIND_TREE_PREFILTER || I.host().spec.kind == WANN_KIND_TREE_VAMANA;
@@ -504,7 +510,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   if (spec) HIP_CHECK(hipMemsetAsync(W.sub_hops.p, 0x7F, ((size_t)nq * maxt) * sizeof(long long), st));
   // (a sub-task slot's count is -1 until its search has finished: what the pollers' scan goes by)
   if (spec) HIP_CHECK(hipMemsetAsync(W.out_cnt.p + (size_t)nq * maxt, 0xFF, (size_t)sub_slots * sizeof(int32_t), st));
-  I.last = wann_counters{};
+  last = wann_counters{};
   if (nq == 0) return;
   HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
   HIP_CHECK(hipMemsetAsync(W.ctr.p, 0, sizeof(Counters), st));
@@ -574,7 +580,7 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
   bool tried_dense = false;
   if (I.host().spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.host().spec.dtype == WANN_DTYPE_F32 && T.gemm &&
       (I.dense_idle < 2 || (I.dense_batches & 7) == 0 || T.dense_always)) {
-    dense_prefilter(I, d_queries, nq, k, st);
+    dense_prefilter(I, W, d_queries, nq, k, st);
     tried_dense = true;
   }
   I.dense_batches++;
@@ -766,9 +772,9 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
       if (nev + 2 > (int)W.ev.size()) throw std::runtime_error("too many search launches in one batch");
       HIP_CHECK(hipEventRecord(W.ev[nev], st));
       if (with_big) {  // first, so that its few workgroups are resident before the ordinary launch fills the CUs
-        HIP_CHECK(hipStreamWaitEvent(I.side_stream, W.ev[nev], 0));
-        if (launch_search(big, big_lc, I.side_stream)) throw HipError(std::string("k_search (big): ") + launch_last_error());
-        HIP_CHECK(hipEventRecord(W.ev_side, I.side_stream));
+        HIP_CHECK(hipStreamWaitEvent(side, W.ev[nev], 0));
+        if (launch_search(big, big_lc, side)) throw HipError(std::string("k_search (big): ") + launch_last_error());
+        HIP_CHECK(hipEventRecord(W.ev_side, side));
       }
       if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
       if (with_big) HIP_CHECK(hipStreamWaitEvent(st, W.ev_side, 0));
@@ -937,37 +943,37 @@ void run_batch(wann_index &I, const float *d_queries, const float *d_ranges, int
 
   float ms = 0.f;
   HIP_CHECK(hipEventElapsedTime(&ms, W.ev[0], W.ev[1]));
-  I.last.device_ms = ms;
+  last.device_ms = ms;
   double sk = 0;
   for (auto &pr : timed) {
     float t = 0.f;
     HIP_CHECK(hipEventElapsedTime(&t, W.ev[pr.first], W.ev[pr.second]));
     sk += t;
   }
-  I.last.search_kernel_ms = sk;
-  I.last.beam_searches = (int64_t)W.h_ctr->beam_searches;
-  I.last.hops = (int64_t)W.h_ctr->hops;
-  I.last.dist_cmps = (int64_t)W.h_ctr->dist_cmps;
-  I.last.brute_rows = (int64_t)W.h_ctr->brute_rows;
-  I.last.label_reads = (int64_t)W.h_ctr->label_reads;
-  I.last.spec_searches = (int64_t)W.h_ctr->spec_searches;
-  I.last.spec_hops = (int64_t)W.h_ctr->spec_hops;
-  I.last.spec_dist_cmps = (int64_t)W.h_ctr->spec_dist_cmps;
-  I.last.rounds = rounds;
-  I.last.recovered_continuations = recovered;
-  I.last.gemm_queries = (int64_t)W.h_ctr->gemm_queries;
+  last.search_kernel_ms = sk;
+  last.beam_searches = (int64_t)W.h_ctr->beam_searches;
+  last.hops = (int64_t)W.h_ctr->hops;
+  last.dist_cmps = (int64_t)W.h_ctr->dist_cmps;
+  last.brute_rows = (int64_t)W.h_ctr->brute_rows;
+  last.label_reads = (int64_t)W.h_ctr->label_reads;
+  last.spec_searches = (int64_t)W.h_ctr->spec_searches;
+  last.spec_hops = (int64_t)W.h_ctr->spec_hops;
+  last.spec_dist_cmps = (int64_t)W.h_ctr->spec_dist_cmps;
+  last.rounds = rounds;
+  last.recovered_continuations = recovered;
+  last.gemm_queries = (int64_t)W.h_ctr->gemm_queries;
   if (tried_dense) I.dense_idle = W.h_ctr->gemm_queries ? 0 : I.dense_idle + 1;
-  I.last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
-  I.last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
-  I.last.deep_handoffs = (int64_t)W.h_ctr->deep_handoffs;
-  I.last.lookaheads_used = (int64_t)W.h_ctr->lookaheads_used;
-  I.last.big_searches = (int64_t)W.h_ctr->big_searches;
-  I.last.big_hops = (int64_t)W.h_ctr->big_hops;
-  I.last.packet_hops = (int64_t)W.h_ctr->packet_hops;
-  I.last.own_scorings = (int64_t)W.h_ctr->own_scorings;
-  I.last.prefetched_hops = (int64_t)W.h_ctr->prefetched_hops;
-  I.last.poll_timeouts = (int64_t)W.h_ctr->poll_timeouts;
-  I.last.lookaheads_issued = (int64_t)W.h_ctr->lookaheads_issued;
+  last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
+  last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
+  last.deep_handoffs = (int64_t)W.h_ctr->deep_handoffs;
+  last.lookaheads_used = (int64_t)W.h_ctr->lookaheads_used;
+  last.big_searches = (int64_t)W.h_ctr->big_searches;
+  last.big_hops = (int64_t)W.h_ctr->big_hops;
+  last.packet_hops = (int64_t)W.h_ctr->packet_hops;
+  last.own_scorings = (int64_t)W.h_ctr->own_scorings;
+  last.prefetched_hops = (int64_t)W.h_ctr->prefetched_hops;
+  last.poll_timeouts = (int64_t)W.h_ctr->poll_timeouts;
+  last.lookaheads_issued = (int64_t)W.h_ctr->lookaheads_issued;
   if (W.h_ctr->unsupported)
     throw std::runtime_error(std::to_string((long long)W.h_ctr->unsupported) +
                              " queries need more than " + std::to_string(maxt) + " partition searches; raise the task slot bound");
@@ -1043,6 +1049,83 @@ BuildSpec make_spec(int kind, int metric, int dtype, int64_t n, int64_t d, int32
 }
 
 }  // namespace
+
+// One batch in flight beside the others: its own workspace, streams and worker thread.  The worker runs the same run_batch
+// the blocking call runs (host-side waits included) -- on ITS stream, so the kernels of two consecutive batches share the GPU:
+// while batch i's last searches finish, batch i+1 is routed and its first workgroups take the compute units that fall free.
+struct wann_index::AsyncLane {
+  Workspace ws;
+  hipStream_t stream = nullptr, side = nullptr;
+  hipEvent_t ready = nullptr;  // the caller's inputs (recorded on the caller's stream at submission)
+  wann_counters last{};
+  struct Job {
+    const float *q, *r;
+    int64_t nq, base;
+    std::string method;
+    wann_query_params qp;
+    uint32_t *ids;
+    float *dists;
+    int64_t ticket;
+  };
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  bool has_job = false, busy = false, stop = false;
+  Job job{};
+  int64_t finished = -1;  // ticket of the last finished job; its outcome:
+  int rc = WANN_OK;
+  std::string err;
+  void loop(wann_index *I) {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return has_job || stop; });
+        if (stop) return;
+        j = job;
+        has_job = false;
+      }
+      int code = WANN_OK;
+      std::string msg;
+      try {
+        HIP_CHECK(hipSetDevice(I->device));
+        HIP_CHECK(hipStreamWaitEvent(stream, ready, 0));
+        run_batch(*I, ws, side, last, j.q, j.r, j.nq, j.base, j.method.c_str(), j.qp, j.ids, j.dists, stream);
+      } catch (HipError &e) {
+        code = WANN_ERR_HIP;
+        msg = e.what();
+      } catch (std::exception &e) {
+        code = WANN_ERR_INVALID;
+        msg = e.what();
+      }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        rc = code;
+        err = msg;
+        finished = j.ticket;
+        busy = false;
+      }
+      cv.notify_all();
+    }
+  }
+  ~AsyncLane() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+    if (stream) (void)hipStreamDestroy(stream);
+    if (side) (void)hipStreamDestroy(side);
+    if (ready) (void)hipEventDestroy(ready);
+  }
+};
+
+wann_index::~wann_index() {
+  lanes.clear();  // (joins the workers before the streams and buffers they use go away)
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+  if (side_stream) (void)hipStreamDestroy(side_stream);
+}
 
 extern "C" {
 
@@ -1139,12 +1222,71 @@ int wann_batch_search_device(wann_index *I, const void *d_queries, const float *
     // (torch's current stream unless changed), so freshly produced inputs / recycled output blocks are safe
     hipStream_t st = (hipStream_t)hip_stream;
     if (I->tune.hooks_live) I->tune = Tuning::from_env();  // WANN_TEST_HOOKS=1 only: tests flip switches between batches
-    run_batch(*I, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st);
+    run_batch(*I, I->ws, I->side_stream, I->last, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st);
   } catch (HipError &e) {
     return fail(WANN_ERR_HIP, e.what());
   } catch (std::exception &e) {
     return fail(WANN_ERR_INVALID, e.what());
   }
+  return WANN_OK;
+}
+
+// Asynchronous form of the device-buffer call (wann.h): tickets are served by kAsyncLanes lanes in turn.
+constexpr int kAsyncLanes = 2;
+
+int wann_batch_search_device_async(wann_index *I, const void *d_queries, const float *d_ranges, int64_t nq, int64_t query_id_base,
+                                   const char *method, const wann_query_params *qp, uint32_t *d_ids, float *d_dists, void *after_stream,
+                                   int64_t *ticket) {
+  if (!I || !qp || nq < 0 || !ticket) return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_device_async");
+  try {
+    std::lock_guard<std::mutex> lk(I->lanes_mu);
+    HIP_CHECK(hipSetDevice(I->device));
+    if (I->tune.hooks_live) I->tune = Tuning::from_env();
+    if (I->lanes.empty())
+      for (int l = 0; l < kAsyncLanes; l++) {
+        std::unique_ptr<wann_index::AsyncLane> L(new wann_index::AsyncLane);
+        int prio_low = 0, prio_high = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIP_CHECK(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithPriority(&L->side, hipStreamNonBlocking, prio_high));
+        HIP_CHECK(hipEventCreateWithFlags(&L->ready, hipEventDisableTiming));
+        wann_index::AsyncLane *lp = L.get();
+        L->th = std::thread([lp, I] { lp->loop(I); });
+        I->lanes.push_back(std::move(L));
+      }
+    const int64_t t = I->next_ticket++;
+    wann_index::AsyncLane &L = *I->lanes[(size_t)(t % kAsyncLanes)];
+    {
+      std::unique_lock<std::mutex> ll(L.m);
+      L.cv.wait(ll, [&] { return !L.busy; });  // (ticket t - kAsyncLanes has finished; wann_wait it BEFORE submitting this one to see its outcome)
+      HIP_CHECK(hipEventRecord(L.ready, (hipStream_t)after_stream));
+      L.job = wann_index::AsyncLane::Job{(const float *)d_queries, d_ranges, nq, query_id_base, method ? method : "", *qp, d_ids, d_dists, t};
+      L.has_job = true;
+      L.busy = true;
+    }
+    L.cv.notify_all();
+    *ticket = t;
+  } catch (HipError &e) {
+    return fail(WANN_ERR_HIP, e.what());
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
+  return WANN_OK;
+}
+
+int wann_wait(wann_index *I, int64_t ticket, wann_counters *out) {
+  if (!I || ticket < 0) return fail(WANN_ERR_INVALID, "invalid argument to wann_wait");
+  wann_index::AsyncLane *L = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(I->lanes_mu);
+    if (I->lanes.empty() || ticket >= I->next_ticket) return fail(WANN_ERR_INVALID, "wann_wait: no such ticket");
+    L = I->lanes[(size_t)(ticket % kAsyncLanes)].get();
+  }
+  std::unique_lock<std::mutex> ll(L->m);
+  L->cv.wait(ll, [&] { return L->finished >= ticket; });
+  if (L->finished != ticket) return fail(WANN_ERR_INVALID, "wann_wait: the ticket's lane has served a later ticket since (wait for ticket t before submitting t + 2)");
+  if (out) *out = L->last;
+  if (L->rc != WANN_OK) return fail(L->rc, L->err);
   return WANN_OK;
 }
 
@@ -1172,7 +1314,7 @@ void search_host_one(wann_index &T, const void *queries, const float *ranges, in
     HIP_CHECK(hipMemcpyAsync(W.q_stage.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
   }
-  run_batch(T, W.q_stage.p, W.r_stage.p, nq, qid_base, method, qp, W.id_stage.p, W.dist_stage.p, st);
+  run_batch(T, W, T.side_stream, T.last, W.q_stage.p, W.r_stage.p, nq, qid_base, method, qp, W.id_stage.p, W.dist_stage.p, st);
   if (nq) {
     HIP_CHECK(hipMemcpyAsync(ids, W.id_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(dists, W.dist_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));

@@ -134,9 +134,36 @@ class Index {
     if (rc) raise_last("batch_search_device failed");
   }
 
+  // asynchronous device-resident call: returns a ticket at once; wait(ticket) blocks until that batch's rows are in place
+  int64_t search_device_async(uint64_t q_ptr, uint64_t r_ptr, int64_t nq, int64_t query_id_base, const std::string &method,
+                              const QueryParams &qp, uint64_t ids_ptr, uint64_t dists_ptr, uint64_t after_stream) {
+    int64_t ticket = -1;
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = wann_batch_search_device_async(h_, (const void *)q_ptr, (const float *)r_ptr, nq, query_id_base, method.c_str(), &qp.c,
+                                          (uint32_t *)ids_ptr, (float *)dists_ptr, (void *)after_stream, &ticket);
+    }
+    if (rc) raise_last("batch_search_device_async failed");
+    return ticket;
+  }
+  py::dict wait(int64_t ticket) {
+    wann_counters c;
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = wann_wait(h_, ticket, &c);
+    }
+    if (rc) raise_last("wait failed");
+    return counters_dict(c);
+  }
+
   py::dict counters() const {
     wann_counters c;
     wann_get_counters(h_, &c);
+    return counters_dict(c);
+  }
+  static py::dict counters_dict(const wann_counters &c) {
     py::dict d;
     d["beam_searches"] = c.beam_searches;
     d["hops"] = c.hops;
@@ -199,6 +226,9 @@ template <typename C>
 static void common_defs(py::class_<C> &c) {
   c.def("batch_search_device", &C::search_device, "queries_ptr"_a, "filters_ptr"_a, "num_queries"_a,
         "query_id_base"_a, "query_method"_a, "query_params"_a, "ids_ptr"_a, "dists_ptr"_a, "stream"_a = 0)
+      .def("batch_search_device_async", &C::search_device_async, "queries_ptr"_a, "filters_ptr"_a, "num_queries"_a, "query_id_base"_a,
+           "query_method"_a, "query_params"_a, "ids_ptr"_a, "dists_ptr"_a, "after_stream"_a = 0)
+      .def("wait", &C::wait, "ticket"_a)
       .def("counters", &C::counters)
       .def("levels", &C::levels)
       .def("partition_range", &C::partition_range)

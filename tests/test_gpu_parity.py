@@ -255,6 +255,52 @@ def test_device_resident_call_matches_host_call(wa, gpu, tmp_path):
     assert np.array_equal(tids.cpu().numpy().view(np.uint32), ids)
 
 
+def test_asynchronous_calls_return_the_blocking_calls_rows(wa, gpu):
+    """wann_batch_search_device_async / wann_wait (ABI 4): batches in flight two at a time on the index's lanes -- different
+    windows, beams and (mid-fraction) scheduling machinery in neighbouring batches -- must give the rows and the work counters of
+    the blocking call, whatever overlaps with whatever; a PrefilterIndex (whose dense-path buffers belong to the index) too."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    n, d, nq = 30000, 64, 1500
+    g = sift_like(n, d, 12)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 13)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=500, split_factor=2, build_params=wa.BuildParams(32, 64, 1.0, ""))
+    pre = wa.PrefilterIndexFloatEuclidian(X, labels)
+    tq = torch.from_numpy(Q).to(dev)
+    batches = [(p, beam, mult) for p in (-7, -3, -5, -1, -9, -4, -6, -2) for beam, mult in ((20, 2),)] + [(-8, 10, 1), (-3, 40, 1)]
+    for index, method in ((idx, "optimized_postfilter"), (pre, "")):
+        want, outs = [], []
+        for i, (p, beam, mult) in enumerate(batches):
+            W = windows(labels, nq, p, 100 + i).astype(np.float32)
+            tw = torch.from_numpy(W).to(dev)
+            ti = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+            td = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            index.batch_search_device(tq.data_ptr(), tw.data_ptr(), nq, 0, method, _qp(wa, beam, mult), ti.data_ptr(), td.data_ptr(), 0)
+            c = index.counters()
+            want.append((ti.cpu().numpy().copy(), td.cpu().numpy().copy(), {k_: c[k_] for k_ in ("beam_searches", "hops", "dist_cmps", "brute_rows")}))
+            outs.append((tw, torch.zeros_like(ti), torch.zeros_like(td)))
+        torch.cuda.synchronize()
+        for rep in range(3):
+            tickets = []
+            for i, (p, beam, mult) in enumerate(batches):
+                tw, ti, td = outs[i]
+                ti.zero_()
+                td.zero_()
+                tickets.append(index.batch_search_device_async(tq.data_ptr(), tw.data_ptr(), nq, 0, method, _qp(wa, beam, mult), ti.data_ptr(), td.data_ptr(), 0))
+                if i >= 1:  # two in flight: wait for ticket i - 1 before submitting i + 1
+                    c = index.wait(tickets[i - 1])
+                    wi, wd, wc = want[i - 1]
+                    assert np.array_equal(outs[i - 1][1].cpu().numpy(), wi), (rep, i - 1, batches[i - 1])
+                    assert np.array_equal(outs[i - 1][2].cpu().numpy(), wd), (rep, i - 1, batches[i - 1])
+                    assert {k_: c[k_] for k_ in wc} == wc, (rep, i - 1, batches[i - 1])
+            c = index.wait(tickets[-1])
+            assert np.array_equal(outs[-1][1].cpu().numpy(), want[-1][0]) and np.array_equal(outs[-1][2].cpu().numpy(), want[-1][1])
+    with pytest.raises(RuntimeError):
+        idx.wait(10 ** 6)  # no such ticket
+
+
 def test_default_stream_call_is_ordered_with_queued_torch_work(wa, gpu):
     """Stream 0 = the HIP default stream: the call is ordered after torch work still queued there (exact
     ground truth by GEMM + topk, whose freed temporaries the caching allocator hands out again as the

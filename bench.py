@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--fractions", default=None, help="'all' = also sweep 2^-16..2^0 (N=1; default for sift), 'headline' = skip, or a list of exponents '-9,-6'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
+    ap.add_argument("--balance", choices=("count", "cost"), default="count",
+                    help="shard cut of a step's batch: equal query counts, or equal predicted work (wann_predict_costs + weighted_bounds; "
+                         "what --scaling strong wants: the step takes as long as its slowest shard)")
     ap.add_argument("--pipeline", type=int, default=2, help="N = 1: also time the rotating batches through the ASYNCHRONOUS call, this many in flight "
                     "(wann_batch_search_device_async; reported as config.pipelined_*, never as `value`); 0 / 1 = skip")
     ap.add_argument("--rotate", type=int, default=4, help="distinct query / window draws the timed steps rotate through (1 = the same batch every step)")
@@ -234,7 +237,7 @@ def main():
     import torch.distributed as dist
     import rangefilteredann_amd  # noqa: F401  (fails loudly when the HIP extension is missing)
     import window_ann as wa
-    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search
+    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search, weighted_bounds
 
     assert torch.cuda.is_available() and wa.device_count() > local_rank, "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
@@ -368,6 +371,11 @@ def main():
     # draws (a step that replays one batch finds the upper tree levels' nodes cache-warm from the step before)
     rot_q = [Qgt] + [torch.from_numpy(Qall[j * gnq:(j + 1) * gnq]).to(dev) for j in range(1, rot)]
     rot_w = [Wgt] + [torch.from_numpy(global_windows(args.fraction, 1000, j)).to(dev) for j in range(1, rot)]
+    # the shard cut of every rotation: equal counts, or equal predicted work (the same cut on every rank: same windows, same index)
+    rot_bounds = [None] * rot
+    if args.balance == "cost" and world > 1:
+        rot_bounds = [weighted_bounds(index.predict_costs(w.cpu().numpy(), method, qp_run), world) for w in rot_w]
+        log("cost-balanced shards (rotation 0):", [b - a for a, b in rot_bounds[0]])
 
     def search_fn(q, r, base, out_ids=None, out_dists=None):
         """local search of one shard: (nq_shard, d) / (nq_shard, 2) device tensors, global number of its first query; the rows
@@ -383,7 +391,7 @@ def main():
 
     def step(j=0):
         # query shards -> HIP batch_search on this rank's GPU -> ONE all-gather of the per-shard top-k over RCCL/xGMI
-        return sharded_batch_search(search_fn, rot_q[j], rot_w[j], K)
+        return sharded_batch_search(search_fn, rot_q[j], rot_w[j], K, bounds=rot_bounds[j])
 
     def timed(rotating):
         """exactly args.steps steps between barrier + synchronize on both sides; MAX over the ranks"""
@@ -498,7 +506,7 @@ def main():
     result = {
         "metric": "QPS @ recall@10>=0.95, window fraction 2^%d" % args.fraction, "value": round(qps, 1), "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "shard_cut": args.balance, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{wl['label']} n={n} d={d} {wl['dist']}, {split}-WST (cutoff {cutoff}, R={R}, L={L}, alpha={alpha}) {method}, "
                                f"window 2^{args.fraction}, {gnq} queries per step ({nq} on rank 0), k={K}",
                    "beam": beam, "final_beam_multiply": mult, "recall_at_10": round(final_recall, 4),

@@ -157,6 +157,13 @@ int wann_batch_search_device_async(wann_index *index, const void *d_queries, con
                                    float *d_dists, void *after_stream, int64_t *ticket);
 int wann_wait(wann_index *index, int64_t ticket, wann_counters *counters);
 
+/* Predicted work of every query of a batch, in beam-search hops (cost[nq], host; ranges: nq x 2 float32, host): the batch is
+ * routed like wann_batch_search routes it (src/range_filter_tree.h:403-471) and every query's tasks are priced with the doubling
+ * loop of src/postfilter_vamana.h:161-181 under "a beam finds k entries once it is expected to hold k in-window points".  What a
+ * strong-scaling shard cut balances: contiguous shards of equal predicted work instead of equal query counts. */
+int wann_predict_costs(wann_index *index, const float *ranges, int64_t nq, const char *method, const wann_query_params *qp,
+                       float *cost);
+
 int wann_get_counters(const wann_index *index, wann_counters *out);
 
 /* Introspection (tests, tools). */
@@ -177,6 +184,17 @@ int64_t wann_device_bytes(const wann_index *index);
  * thread + stream per replica; queries keep their global row numbers.  wann_batch_search_device serves the primary only.
  * Returns the number of replicas (1 without WANN_DEVICES). */
 int wann_num_replicas(const wann_index *index);
+
+/* The multi-device call with DEVICE-RESIDENT gathered rows (ABI 4), for a host that keeps working on the GPUs: every replica of
+ * WANN_DEVICES (distinct devices: one RCCL rank each) searches its contiguous shard -- wann_gather_layout gives shard s's first
+ * row, row count and the common capacity cap = ceil(nq / replicas) -- and ONE ncclAllGather over RCCL / xGMI leaves, on EVERY
+ * replica's device, the planes of all shards:   d_planes[r] -> int32 [replicas][2][cap][k]   (device memory of replica r, owned
+ * by the index, valid until its next call): plane [s][0] = ids (uint32) of shard s's rows, plane [s][1] = their distances
+ * (float32 bits); rows beyond a shard's count are the reference's padding (id 0, FLT_MAX).  Global query q of shard s sits at
+ * row q - lo_s.  queries / ranges: host buffers like wann_batch_search.  librccl.so is opened at the first call (dlopen). */
+int wann_gather_layout(int64_t nq, int world, int shard, int64_t *lo, int64_t *count, int64_t *cap);
+int wann_batch_search_allgather(wann_index *index, const void *queries, const float *ranges, int64_t nq, const char *method,
+                                const wann_query_params *qp, int32_t **d_planes, int64_t *cap);
 
 /* Graph-cache tool: build (host, multi-threaded) and save only the cache files of the
  * partitions p with p % nshards == shard, without creating a device index.  Used to split the

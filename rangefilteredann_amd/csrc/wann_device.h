@@ -238,6 +238,15 @@ struct BruteArgs {
   int64_t part_cap, part_slots;  // capacity of part_key (keys) and of part_cnt (slices)
 };
 
+struct CostArgs {  // k_task_cost: predicted work of every query of a routed batch (hops; an exact scan's rows count 1/36 each)
+  const Task *tasks;
+  const int32_t *qtask_cnt;
+  const PartDesc *parts;
+  int64_t nq;
+  int32_t maxt, k, beam, max_beam, mult;
+  float *cost;  // [nq]
+};
+
 struct FinalizeArgs {
   IndexView ix;
   const Task *tasks;
@@ -264,6 +273,7 @@ int launch_order_heavy(const OrderArgs &a, void *stream);
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);
 int launch_brute(const BruteArgs &a, int blocks, void *stream);
 int launch_finalize(const FinalizeArgs &a, void *stream);
+int launch_task_cost(const CostArgs &a, void *stream);
 // bytes of LDS one wave of k_search needs: common scratch + the beam / seen-filter pool
 int search_lds_bytes_per_wave(int stride, int pool_bytes);
 const char *launch_last_error();

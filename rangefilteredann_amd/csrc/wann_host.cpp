@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <unistd.h>
 #include <memory>
 #include <condition_variable>
@@ -27,6 +28,8 @@
 #include "wann_gpu_build.h"
 #include "wann_hip_util.h"
 #include "wann_tuning.h"
+
+#include <rccl/rccl.h>  // types only: librccl.so is opened at first use (wann_batch_search_allgather), never linked
 
 using namespace wann;
 
@@ -82,6 +85,7 @@ struct Workspace {
   DevBuf<Counters> ctr;
   DevBuf<float> q_stage, r_stage, dist_stage;
   DevBuf<uint32_t> id_stage;
+  DevBuf<int32_t> gat_send, gat_recv;  // wann_batch_search_allgather: this replica's [2][cap][k] planes / everybody's [world][2][cap][k]
   int32_t big_stride = 0;
   int32_t *h_ints = nullptr;  // pinned
   Counters *h_ctr = nullptr;  // pinned
@@ -171,6 +175,8 @@ struct wann_index {
   std::mutex dense_mu;  // the dense prefilter path's buffers and counters belong to the index: one batch at a time uses them
   // wann_batch_search_device_async: further LANES -- a lane is everything one batch in flight needs (workspace, streams, a
   // worker thread); the blocking calls use the members above
+  struct Rccl;                 // librccl.so + one communicator per replica (wann_batch_search_allgather)
+  std::unique_ptr<Rccl> rccl;
   struct AsyncLane;
   std::vector<std::unique_ptr<AsyncLane>> lanes;
   std::mutex lanes_mu;
@@ -1121,7 +1127,47 @@ struct wann_index::AsyncLane {
   }
 };
 
+// RCCL, opened with dlopen at first use: a host that never gathers on the device never loads it.
+struct wann_index::Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::vector<ncclComm_t> comms;
+  void open(const std::vector<int> &devices) {
+    lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) throw std::runtime_error(std::string("cannot open librccl.so: ") + dlerror());
+    auto sym = [&](const char *n) {
+      void *p = dlsym(lib, n);
+      if (!p) throw std::runtime_error(std::string("librccl.so lacks ") + n);
+      return p;
+    };
+    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    AllGather = (decltype(AllGather))sym("ncclAllGather");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    comms.assign(devices.size(), nullptr);
+    check(CommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+  }
+  void check(ncclResult_t r, const char *what) const {
+    if (r != ncclSuccess) throw HipError(std::string(what) + ": " + (GetErrorString ? GetErrorString(r) : "RCCL error"));
+  }
+  ~Rccl() {
+    if (CommDestroy)
+      for (ncclComm_t c : comms)
+        if (c) (void)CommDestroy(c);
+    // (the library stays loaded: its teardown at dlclose is not worth the risk at process exit)
+  }
+};
+
 wann_index::~wann_index() {
+  rccl.reset();
   lanes.clear();  // (joins the workers before the streams and buffers they use go away)
   if (own_stream) (void)hipStreamDestroy(own_stream);
   if (side_stream) (void)hipStreamDestroy(side_stream);
@@ -1287,6 +1333,192 @@ int wann_wait(wann_index *I, int64_t ticket, wann_counters *out) {
   if (L->finished != ticket) return fail(WANN_ERR_INVALID, "wann_wait: the ticket's lane has served a later ticket since (wait for ticket t before submitting t + 2)");
   if (out) *out = L->last;
   if (L->rc != WANN_OK) return fail(L->rc, L->err);
+  return WANN_OK;
+}
+
+// Shard `shard` of `world` contiguous shards of an nq-query batch (the cut of wann_batch_search's multi-device mode and of
+// wann_batch_search_allgather): first row, row count, and the common plane capacity.
+int wann_gather_layout(int64_t nq, int world, int shard, int64_t *lo, int64_t *count, int64_t *cap) {
+  if (nq < 0 || world <= 0 || shard < 0 || shard >= world) return fail(WANN_ERR_INVALID, "invalid argument to wann_gather_layout");
+  const int64_t base = nq / world, rem = nq % world;
+  if (lo) *lo = shard * base + std::min<int64_t>(shard, rem);
+  if (count) *count = base + (shard < rem ? 1 : 0);
+  if (cap) *cap = base + (rem ? 1 : 0);
+  return WANN_OK;
+}
+
+// The in-process multi-device call with DEVICE-RESIDENT, gathered result rows: every replica searches its shard into its send
+// planes and ONE ncclAllGather (RCCL over xGMI, a communicator per replica, one group call) leaves all shards' planes on every
+// replica's device.
+int wann_batch_search_allgather(wann_index *I, const void *queries, const float *ranges, int64_t nq, const char *method,
+                                const wann_query_params *qp, int32_t **d_planes, int64_t *cap_out) {
+  if (!I || !qp || nq < 0 || !d_planes || !cap_out || (nq > 0 && (!queries || !ranges)))
+    return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_allgather");
+  if (qp->k <= 0 || qp->k > 1024) return fail(WANN_ERR_INVALID, "k must be in [1, 1024]");
+  const int G = 1 + (int)I->replicas.size();
+  std::vector<wann_index *> reps{I};
+  for (auto &R : I->replicas) reps.push_back(R.get());
+  std::vector<int> devs;
+  for (wann_index *T : reps) devs.push_back(T->device);
+  for (int a = 0; a < G; a++)
+    for (int b = a + 1; b < G; b++)
+      if (devs[a] == devs[b]) return fail(WANN_ERR_UNSUPPORTED, "wann_batch_search_allgather needs DISTINCT devices in WANN_DEVICES (one RCCL rank per device)");
+  try {
+    if (!I->rccl) {
+      std::unique_ptr<wann_index::Rccl> r(new wann_index::Rccl);
+      r->open(devs);
+      I->rccl = std::move(r);
+    }
+    const int64_t k = qp->k, d = I->H.spec.d, esz = I->dtype == WANN_DTYPE_F32 ? 4 : 1;
+    int64_t cap = 0;
+    wann_gather_layout(nq, G, 0, nullptr, nullptr, &cap);
+    if (cap == 0) cap = 1;
+    std::vector<std::thread> threads;
+    std::vector<int> codes((size_t)G, WANN_OK);
+    std::vector<std::string> errs((size_t)G);
+    for (int g = 0; g < G; g++) {
+      wann_index *T = reps[(size_t)g];
+      int64_t lo = 0, cnt = 0;
+      wann_gather_layout(nq, G, g, &lo, &cnt, nullptr);
+      threads.emplace_back([=, &codes, &errs] {
+        try {
+          std::lock_guard<std::mutex> lk(T->mu);
+          HIP_CHECK(hipSetDevice(T->device));
+          if (T->tune.hooks_live) T->tune = Tuning::from_env();
+          Workspace &W = T->ws;
+          hipStream_t st = T->own_stream;
+          W.gat_send.ensure((size_t)(2 * cap * k));
+          W.gat_recv.ensure((size_t)((int64_t)G * 2 * cap * k));
+          W.q_stage.ensure((size_t)std::max<int64_t>(cnt * d, 1));
+          W.r_stage.ensure((size_t)std::max<int64_t>(cnt * 2, 1));
+          std::vector<float> qf;
+          const void *qsrc = (const char *)queries + lo * d * esz;
+          if (cnt && T->dtype != WANN_DTYPE_F32) {
+            qf = bytes_to_float(T->dtype, qsrc, cnt * d);
+            qsrc = qf.data();
+          }
+          if (cnt) {
+            HIP_CHECK(hipMemcpyAsync(W.q_stage.p, qsrc, (size_t)cnt * d * 4, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges + 2 * lo, (size_t)cnt * 8, hipMemcpyHostToDevice, st));
+          }
+          int32_t *ids_plane = W.gat_send.p, *dist_plane = W.gat_send.p + cap * k;
+          // rows beyond this shard's count: the padding of the reference's result rows (id 0 / FLT_MAX)
+          if (cnt < cap) {
+            HIP_CHECK(hipMemsetAsync(ids_plane + cnt * k, 0, (size_t)((cap - cnt) * k) * 4, st));
+            HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(dist_plane + cnt * k), 0x7f7fffff, (size_t)((cap - cnt) * k), st));
+          }
+          run_batch(*T, W, T->side_stream, T->last, W.q_stage.p, W.r_stage.p, cnt, lo, method, *qp, (uint32_t *)ids_plane, (float *)dist_plane, st);
+        } catch (HipError &e) {
+          codes[(size_t)g] = WANN_ERR_HIP;
+          errs[(size_t)g] = e.what();
+        } catch (std::exception &e) {
+          codes[(size_t)g] = WANN_ERR_INVALID;
+          errs[(size_t)g] = e.what();
+        }
+      });
+    }
+    for (auto &t : threads) t.join();
+    for (int g = 0; g < G; g++)
+      if (codes[(size_t)g] != WANN_OK) return fail(codes[(size_t)g], "replica " + std::to_string(g) + ": " + errs[(size_t)g]);
+    // one all-gather of the [2][cap][k] planes, all replicas in one group call
+    wann_index::Rccl &N = *I->rccl;
+    N.check(N.GroupStart(), "ncclGroupStart");
+    for (int g = 0; g < G; g++) {
+      wann_index *T = reps[(size_t)g];
+      HIP_CHECK(hipSetDevice(T->device));
+      N.check(N.AllGather(T->ws.gat_send.p, T->ws.gat_recv.p, (size_t)(2 * cap * k), ncclInt32, N.comms[(size_t)g], T->own_stream), "ncclAllGather");
+    }
+    N.check(N.GroupEnd(), "ncclGroupEnd");
+    for (int g = 0; g < G; g++) {
+      wann_index *T = reps[(size_t)g];
+      HIP_CHECK(hipSetDevice(T->device));
+      HIP_CHECK(hipStreamSynchronize(T->own_stream));
+      d_planes[g] = T->ws.gat_recv.p;
+    }
+    HIP_CHECK(hipSetDevice(I->device));
+    *cap_out = cap;
+  } catch (HipError &e) {
+    return fail(WANN_ERR_HIP, e.what());
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
+  return WANN_OK;
+}
+
+// Predicted work of every query of a batch (wann.h): the batch is routed on the device without speculative levels and
+// k_task_cost prices each query's tasks.  A planning call (one small launch pair and a copy), not part of the search.
+int wann_predict_costs(wann_index *I, const float *ranges, int64_t nq, const char *method, const wann_query_params *qp, float *cost) {
+  if (!I || !qp || nq < 0 || (nq > 0 && (!ranges || !cost))) return fail(WANN_ERR_INVALID, "invalid argument to wann_predict_costs");
+  if (nq == 0) return WANN_OK;
+  std::lock_guard<std::mutex> lk(I->mu);
+  try {
+    HIP_CHECK(hipSetDevice(I->device));
+    Workspace &W = I->ws;
+    const int mcode = method_code(method);
+    const bool tree = I->host().spec.kind == WANN_KIND_TREE_PREFILTER || I->host().spec.kind == WANN_KIND_TREE_VAMANA;
+    const bool single = !tree || (mcode == M_OPTIMIZED && !qp->has_min_query_to_bucket_ratio && I->host().spec.split_factor <= 4);
+    const int maxt = single ? 1 : 96;
+    const int k = (int)std::max<int64_t>(1, std::min<int64_t>(qp->k, 1024));
+    W.ensure(nq, k, maxt, 0);
+    W.r_stage.ensure((size_t)nq * 2);
+    W.dist_stage.ensure((size_t)nq);
+    hipStream_t st = I->own_stream;
+    HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
+    HIP_CHECK(hipMemsetAsync(W.ctr.p, 0, sizeof(Counters), st));
+    RouteArgs ra{};
+    ra.ix = I->view;
+    ra.ranges = W.r_stage.p;
+    ra.nq = nq;
+    ra.method = mcode;
+    ra.maxt = maxt;
+    ra.qtask_cnt = W.qtask_cnt.p;
+    ra.k = k;
+    ra.beam = (int32_t)std::min<int64_t>(std::max<int64_t>(qp->beam_width, 1), INT32_MAX);
+    ra.max_beam = (int32_t)std::min<int64_t>(qp->postfiltering_max_beam, INT32_MAX);
+    ra.has_ratio = qp->has_min_query_to_bucket_ratio;
+    ra.ratio = qp->min_query_to_bucket_ratio;
+    ra.tasks = W.tasks.p;
+    ra.graph_list = W.list_a.p;
+    ra.graph_count = W.ints.p + I_GRAPH_COUNT;
+    ra.heavy_list = W.list_heavy.p;
+    ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
+    ra.heavy_cap = W.big_stride;
+    ra.mid_list = W.list_mid.p;
+    ra.mid_count = W.ints.p + I_MID_COUNT;
+    ra.heavy_ratio = I->tune.heavy_ratio;
+    ra.risk_count = W.ints.p + I_RISK;
+    ra.brute_list = W.list_brute.p;
+    ra.brute_count = W.ints.p + I_BRUTE_COUNT;
+    ra.spec = 0;  // (plain tasks only: each carries its window's size)
+    ra.spec_num = I->tune.spec_num;
+    ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp->beam_width);
+    ra.sub_base0 = ra.sub_cap = (int32_t)(nq * maxt);
+    ra.sub_count = W.ints.p + I_SUB_COUNT;
+    ra.big_list = W.list_big.p;
+    ra.big_count = W.ints.p + I_BIG_COUNT;
+    ra.big_stride = W.big_stride;
+    ra.ctr = W.ctr.p;
+    if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
+    CostArgs ca{};
+    ca.tasks = W.tasks.p;
+    ca.qtask_cnt = W.qtask_cnt.p;
+    ca.parts = I->view.parts;
+    ca.nq = nq;
+    ca.maxt = maxt;
+    ca.k = k;
+    ca.beam = ra.beam;
+    ca.max_beam = ra.max_beam;
+    ca.mult = (int32_t)std::min<int64_t>(std::max<int64_t>(qp->final_beam_multiply, 1), INT32_MAX);
+    ca.cost = W.dist_stage.p;
+    if (launch_task_cost(ca, st)) throw HipError(std::string("k_task_cost: ") + launch_last_error());
+    HIP_CHECK(hipMemcpyAsync(cost, W.dist_stage.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  } catch (HipError &e) {
+    return fail(WANN_ERR_HIP, e.what());
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
   return WANN_OK;
 }
 

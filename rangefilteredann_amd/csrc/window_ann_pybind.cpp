@@ -147,6 +147,20 @@ class Index {
     if (rc) raise_last("batch_search_device_async failed");
     return ticket;
   }
+  // predicted work per query (hops) of a batch of windows: what a cost-balanced shard cut balances
+  py::array_t<float> predict_costs(py::array_t<float, py::array::c_style | py::array::forcecast> filters, const std::string &method,
+                                   const QueryParams &qp) {
+    if (filters.ndim() != 2 || filters.shape(1) != 2) throw std::runtime_error("filters must be (num_queries, 2)");
+    const int64_t nq = filters.shape(0);
+    py::array_t<float> out(nq);
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = wann_predict_costs(h_, filters.data(), nq, method.c_str(), &qp.c, out.mutable_data());
+    }
+    if (rc) raise_last("predict_costs failed");
+    return out;
+  }
   py::dict wait(int64_t ticket) {
     wann_counters c;
     int rc;
@@ -229,6 +243,7 @@ static void common_defs(py::class_<C> &c) {
       .def("batch_search_device_async", &C::search_device_async, "queries_ptr"_a, "filters_ptr"_a, "num_queries"_a, "query_id_base"_a,
            "query_method"_a, "query_params"_a, "ids_ptr"_a, "dists_ptr"_a, "after_stream"_a = 0)
       .def("wait", &C::wait, "ticket"_a)
+      .def("predict_costs", &C::predict_costs, "filters"_a, "query_method"_a, "query_params"_a)
       .def("counters", &C::counters)
       .def("levels", &C::levels)
       .def("partition_range", &C::partition_range)

@@ -10,10 +10,19 @@ RCCL/xGMI (torch.distributed backend "nccl" on ROCm) -- 8 bytes * k per query, l
 
 `search_fn(q_shard, r_shard, query_id_base) -> (ids, dists)` does the local search, so the same
 code runs on CPU tensors under the gloo backend in the tests.
+
+Shard cuts.  By default every rank gets the same NUMBER of queries (`shard_bounds`).  For one batch cut N
+ways (strong scaling) the batch's time is the slowest shard's, and a query's work varies by two orders of
+magnitude with its window (a window that is 1/512 of its partition needs a beam of thousands): `weighted_bounds`
+cuts contiguous shards of equal predicted WORK instead (prefix sums of per-query costs, e.g.
+`index.predict_costs(windows, method, query_params)` = wann_predict_costs) -- still contiguous, so global query
+numbers survive.  Every rank must compute the same cut (same costs in, same bounds out: pure integer /
+float64 arithmetic on identical inputs).
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+import inspect
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -30,31 +39,75 @@ def shard_capacity(nq: int, world: int) -> int:
     return (nq + world - 1) // world
 
 
+def weighted_bounds(costs: Sequence[float], world: int) -> List[Tuple[int, int]]:
+    """`world` contiguous shards [lo, hi) of about equal total cost: shard r ends at the first query whose prefix sum reaches
+    (r + 1) / world of the total.  Every shard gets at least one query while there are queries left for the shards after it;
+    with nq < world the last shards are empty.  Deterministic: float64 prefix sums of the given costs."""
+    import numpy as np
+    c = np.maximum(np.asarray(costs, dtype=np.float64), 0.0)
+    nq = int(c.shape[0])
+    if nq == 0:
+        return [(0, 0)] * world
+    pre = np.cumsum(c)
+    total = float(pre[-1])
+    if not total > 0.0:
+        return [shard_bounds(nq, world, r) for r in range(world)]
+    bounds, lo = [], 0
+    for r in range(world):
+        if r == world - 1:
+            hi = nq
+        else:
+            hi = int(np.searchsorted(pre, total * (r + 1) / world, side="left")) + 1  # the query that crosses the target stays in r
+            hi = max(hi, lo + 1)                   # at least one query ...
+            hi = min(hi, nq - (world - 1 - r))     # ... and one left for each shard after this one (when there are enough)
+            hi = max(hi, lo)
+        hi = min(hi, nq)
+        bounds.append((lo, hi))
+        lo = hi
+    return bounds
+
+
 def sharded_batch_search(search_fn: Callable, queries: torch.Tensor, ranges: torch.Tensor, k: int,
-                         pad_id: int = 0, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                         pad_id: int = 0, group=None, bounds: Optional[Sequence[Tuple[int, int]]] = None,
+                         writes_outputs: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Search `queries` (nq, d) / `ranges` (nq, 2) -- identical on every rank -- by shards and return
     the full (nq, k) ids (int32 view of uint32) and dists on every rank.
 
-    `search_fn(q_shard, r_shard, query_id_base[, out_ids, out_dists])`: a search function that takes the two output
-    tensors ((m, k) int32 / float32, contiguous) writes its rows straight into the all-gather's send buffer; one that
-    does not returns `(ids, dists)` and they are copied there."""
+    `search_fn(q_shard, r_shard, query_id_base[, out_ids=, out_dists=])`: a search function with parameters NAMED
+    `out_ids` / `out_dists` ((m, k) int32 / float32, contiguous) is handed the all-gather's send planes by keyword and writes
+    its rows straight into them (`writes_outputs` overrides the detection); one without returns `(ids, dists)` and they are
+    copied there.
+
+    `bounds`: the shard cut, one (lo, hi) per rank, contiguous and covering [0, nq) -- the SAME list on every rank (e.g.
+    `weighted_bounds`); default: equal query counts."""
     grouped = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if grouped else 1
     rank = dist.get_rank(group) if grouped else 0
     nq = queries.shape[0]
-    lo, hi = shard_bounds(nq, world, rank)
-    takes_out = _takes_outputs(search_fn)
-    if not grouped:  # no process group: one process, one GPU.  (A group of ONE rank still runs the collective.)
-        return search_fn(queries[lo:hi], ranges[lo:hi], lo)[:2]
-    cap = shard_capacity(nq, world)
+    if bounds is None:
+        bounds = [shard_bounds(nq, world, r) for r in range(world)]
+    bounds = [(int(a), int(b)) for a, b in bounds]
+    if len(bounds) != world or bounds[0][0] != 0 or bounds[-1][1] != nq or any(bounds[i][1] != bounds[i + 1][0] for i in range(world - 1)) \
+            or any(b < a for a, b in bounds):
+        raise ValueError(f"bounds must be {world} contiguous shards covering [0, {nq}): {bounds}")
+    lo, hi = bounds[rank]
+    takes_out = _takes_outputs(search_fn) if writes_outputs is None else bool(writes_outputs)
     dev = queries.device
-    # send = [ids plane | dists plane], each (cap, k) and contiguous: the search writes into them; short shards (at most one
-    # row short) are padded because all-gather needs equal sizes
+    if not grouped:  # no process group: one process, one GPU.  (A group of ONE rank still runs the collective.)
+        if takes_out:
+            out_ids = torch.empty((hi - lo, k), dtype=torch.int32, device=dev)
+            out_d = torch.empty((hi - lo, k), dtype=torch.float32, device=dev)
+            search_fn(queries[lo:hi], ranges[lo:hi], lo, out_ids=out_ids, out_dists=out_d)
+            return out_ids, out_d
+        return search_fn(queries[lo:hi], ranges[lo:hi], lo)[:2]
+    cap = max(b - a for a, b in bounds)
+    # send = [ids plane | dists plane], each (cap, k) and contiguous: the search writes into them; shorter shards are padded
+    # because all-gather needs equal sizes
     send = torch.empty((2, cap, k), dtype=torch.int32, device=dev)
     if takes_out:
-        search_fn(queries[lo:hi], ranges[lo:hi], lo, send[0, : hi - lo], send[1, : hi - lo].view(torch.float32))
+        search_fn(queries[lo:hi], ranges[lo:hi], lo, out_ids=send[0, : hi - lo], out_dists=send[1, : hi - lo].view(torch.float32))
     else:
-        ids, dists = search_fn(queries[lo:hi], ranges[lo:hi], lo)
+        ids, dists = search_fn(queries[lo:hi], ranges[lo:hi], lo)[:2]
         send[0, : hi - lo] = ids.view(torch.int32)
         send[1, : hi - lo] = dists.view(torch.int32)
     if hi - lo < cap:
@@ -62,22 +115,23 @@ def sharded_batch_search(search_fn: Callable, queries: torch.Tensor, ranges: tor
         send[1, hi - lo:] = torch.tensor(torch.finfo(torch.float32).max).view(torch.int32)
     recv = torch.empty((world, 2, cap, k), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(recv.view(world * 2 * cap, k), send.view(2 * cap, k), group=group)
-    if nq == world * cap:  # equal shards: the gathered planes ARE the result rows, rank after rank
+    if all(b - a == cap for a, b in bounds):  # equal shards: the gathered planes ARE the result rows, rank after rank
         if world == 1:
             return recv[0, 0], recv[0, 1].view(torch.float32)
         return recv[:, 0].reshape(nq, k), recv[:, 1].reshape(nq, k).view(torch.float32)
     out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    for r in range(world):
-        a, b = shard_bounds(nq, world, r)
+    for r, (a, b) in enumerate(bounds):
         out_ids[a:b] = recv[r, 0, : b - a]
         out_d[a:b] = recv[r, 1, : b - a].view(torch.float32)
     return out_ids, out_d
 
 
 def _takes_outputs(fn) -> bool:
-    import inspect
+    """Does the search function declare parameters named out_ids AND out_dists?  (By NAME: a function with five parameters for
+    other reasons -- k, a stream -- must not be handed tensors in those slots.)"""
     try:
-        return len(inspect.signature(fn).parameters) >= 5
+        params = inspect.signature(fn).parameters
     except (TypeError, ValueError):
         return False
+    return "out_ids" in params and "out_dists" in params

@@ -127,3 +127,21 @@ def test_four_wave_search_kernels_fit_two_waves_per_simd(wa):
     assert len(lean) == 12  # (2 kernels x 2 metrics x 3 element types)
     for l in lean:
         assert int(l.split("vgpr+agpr")[1].split()[0]) <= 256, l
+
+
+def test_gather_layout_is_the_contiguous_balanced_cut():
+    """wann_gather_layout (no GPU needed): the shard arithmetic of the multi-device calls equals distributed.shard_bounds, the
+    capacity is the longest shard, and bad arguments are refused"""
+    import ctypes as C
+    import rangefilteredann_amd
+    from rangefilteredann_amd.distributed import shard_bounds, shard_capacity
+    lib = C.CDLL(rangefilteredann_amd.lib_path())
+    lib.wann_gather_layout.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    for nq in (0, 1, 7, 8, 333, 10000, 10001):
+        for world in (1, 2, 3, 8):
+            for s_ in range(world):
+                lo, cnt, cap = C.c_int64(-1), C.c_int64(-1), C.c_int64(-1)
+                assert lib.wann_gather_layout(nq, world, s_, C.byref(lo), C.byref(cnt), C.byref(cap)) == 0
+                a, b = shard_bounds(nq, world, s_)
+                assert (lo.value, lo.value + cnt.value) == (a, b) and cap.value == shard_capacity(nq, world)
+    assert lib.wann_gather_layout(10, 0, 0, None, None, None) != 0 and lib.wann_gather_layout(10, 2, 2, None, None, None) != 0

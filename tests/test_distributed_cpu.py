@@ -20,14 +20,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nq, out_dir, direct=False):
+def _worker(rank, world, port, nq, out_dir, direct=False, weighted=False):
     import sys
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WANN_NO_TORCH="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as orc
-    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search
+    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search, weighted_bounds
     n, d = 1500, 32
     g = sift_like(n, d, 1)
     X, Q = g(n), g(nq)
@@ -56,8 +56,13 @@ def _worker(rank, world, port, nq, out_dir, direct=False):
         ids, dists = idx.batch_search(full_q, full_r, base + q.shape[0], "optimized_postfilter", qp)
         return torch.from_numpy(ids[base:].view(np.int32).copy()), torch.from_numpy(dists[base:].copy())
 
-    ids, dists = sharded_batch_search(search_direct if direct else search_plain, torch.from_numpy(Q), torch.from_numpy(W), 10)
-    lo, hi = shard_bounds(nq, world, rank)
+    bounds = None
+    if weighted:  # a cost-balanced cut: the first queries are "heavy" -- uneven shard sizes, the same cut on every rank
+        costs = np.where(np.arange(nq) < nq // 5, 40.0, 1.0) + (np.arange(nq) % 7)
+        bounds = weighted_bounds(costs, world)
+        assert len({b - a for a, b in bounds}) > 1
+    ids, dists = sharded_batch_search(search_direct if direct else search_plain, torch.from_numpy(Q), torch.from_numpy(W), 10, bounds=bounds)
+    lo, hi = bounds[rank] if bounds else shard_bounds(nq, world, rank)
     assert calls == [(lo, hi - lo)]
     eids, edists = idx.batch_search(Q, W, nq, "optimized_postfilter", qp)
     ok = np.array_equal(ids.numpy().view(np.uint32), eids) and np.array_equal(dists.numpy(), edists)
@@ -71,6 +76,44 @@ def test_two_rank_sharded_search_equals_single_process(oracle, tmp_path, nq, dir
     mp.spawn(_worker, args=(world, _free_port(), nq, str(tmp_path), direct), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"ok{r}").read() == "1"
+
+
+@pytest.mark.parametrize("world,nq,direct", [(4, 61, False), (4, 64, True), (8, 45, True)])
+def test_cost_balanced_shards_on_four_and_eight_ranks(oracle, tmp_path, world, nq, direct):
+    """the strong-scaling cut (weighted_bounds: contiguous shards of equal predicted work, uneven sizes, odd batch sizes) through
+    the same all-gather on 4 and 8 gloo ranks: every rank ends with every row of the single-process search"""
+    mp.spawn(_worker, args=(world, _free_port(), nq, str(tmp_path), direct, True), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"ok{r}").read() == "1"
+
+
+def test_weighted_bounds_balance_and_cover():
+    from rangefilteredann_amd.distributed import weighted_bounds
+    rng = np.random.default_rng(3)
+    for nq in (0, 1, 3, 8, 1000, 10001):
+        for world in (1, 2, 3, 8):
+            for law in ("flat", "skewed", "zeros", "one_giant"):
+                c = {"flat": np.ones(nq), "skewed": rng.pareto(1.2, nq) + 0.01, "zeros": np.zeros(nq),
+                     "one_giant": np.where(np.arange(nq) == nq // 2, 1e6, 1.0)}[law]
+                b = weighted_bounds(c, world)
+                assert len(b) == world and b[0][0] == 0 and b[-1][1] == nq
+                assert all(b[i][1] == b[i + 1][0] for i in range(world - 1)) and all(hi >= lo for lo, hi in b)
+                if nq >= world:
+                    assert all(hi > lo for lo, hi in b), (nq, world, law, b)
+                if nq and law in ("flat", "skewed"):  # no shard carries more than its share plus one query's cost
+                    tot, mx = float(c.sum()), float(c.max())
+                    assert max(float(c[lo:hi].sum()) for lo, hi in b) <= tot / world + mx + 1e-9
+                assert b == weighted_bounds(c.astype(np.float32), world) or law == "skewed"  # (deterministic for identical inputs)
+    assert weighted_bounds(c, 4) == weighted_bounds(c.copy(), 4)
+
+
+def test_output_planes_are_detected_by_parameter_name():
+    from rangefilteredann_amd.distributed import _takes_outputs
+    assert _takes_outputs(lambda q, r, base, out_ids=None, out_dists=None: None)
+    assert _takes_outputs(lambda q, r, base, out_ids, out_dists: None)
+    assert not _takes_outputs(lambda q, r, base, k, stream: None)       # five parameters for other reasons
+    assert not _takes_outputs(lambda q, r, base: None)
+    assert not _takes_outputs(lambda q, r, base, out_ids=None: None)    # both or neither
 
 
 def test_shard_bounds_cover_everything():

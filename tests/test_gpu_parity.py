@@ -785,6 +785,95 @@ def test_c_abi_end_to_end_through_ctypes(oracle, wa, gpu, tmp_path):
         lib.wann_index_destroy(h)
 
 
+def test_predicted_costs_follow_the_work(wa, gpu):
+    """wann_predict_costs (what a cost-balanced shard cut balances): deterministic, positive, and its batch total tracks the
+    work the search then does (hops + scanned rows / 36) across window fractions within a small factor; a cut of equal
+    predicted work is a valid cut"""
+    from rangefilteredann_amd.distributed import weighted_bounds
+    n, d, nq = 40000, 32, 600
+    g = sift_like(n, d, 51)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 17)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=500, split_factor=2, build_params=wa.BuildParams(32, 64, 1.0, ""))
+    qp = _qp(wa, 20, 1)
+    tot = {}
+    for p in (-1, -4, -6, -8, -11):
+        W = windows(labels, nq, p, 60 + p).astype(np.float32)
+        c1 = idx.predict_costs(W, "optimized_postfilter", qp)
+        c2 = idx.predict_costs(W, "optimized_postfilter", qp)
+        assert c1.shape == (nq,) and np.array_equal(c1, c2) and (c1 > 0).all()
+        idx.batch_search(Q, W, nq, "optimized_postfilter", qp)
+        c = idx.counters()
+        work = c["hops"] + c["spec_hops"] * 0 + c["brute_rows"] / 36.0 + nq * (c["brute_rows"] > 0)
+        tot[p] = (float(c1.sum()), work)
+        assert 0.33 < tot[p][0] / max(work, 1.0) < 3.0, (p, tot[p])
+        b = weighted_bounds(c1, 8)
+        assert b[0][0] == 0 and b[-1][1] == nq and all(b[i][1] == b[i + 1][0] for i in range(7))
+        assert max(float(c1[lo:hi].sum()) for lo, hi in b) <= float(c1.sum()) / 8 + float(c1.max()) + 1e-3
+    f = idx.predict_costs(windows(labels, nq, -5, 1).astype(np.float32), "fenwick", qp)  # (multi-task queries)
+    assert (f > 0).all()
+
+
+def test_c_abi_allgather_leaves_device_resident_rows(wa, gpu, tmp_path):
+    """wann_batch_search_allgather (ABI 4): the shard search writes into the all-gather's send planes, ONE ncclAllGather (RCCL,
+    opened with dlopen) leaves [replicas][2][cap][k] planes on the device, and the rows read back from them equal
+    wann_batch_search's.  One GPU here: a group of one rank -- the communicator, the collective and the plane layout are real."""
+    import ctypes as C
+    import rangefilteredann_amd
+    lib = C.CDLL(rangefilteredann_amd.lib_path())
+    hip = C.CDLL("libamdhip64.so")
+
+    class QP(C.Structure):
+        _fields_ = [("k", C.c_int64), ("beam_width", C.c_int64), ("cut", C.c_double), ("limit", C.c_int64), ("degree_limit", C.c_int64),
+                    ("final_beam_multiply", C.c_int64), ("postfiltering_max_beam", C.c_int64), ("has_ratio", C.c_int32), ("ratio", C.c_float),
+                    ("verbose", C.c_int32)]
+
+    class BP(C.Structure):
+        _fields_ = [("max_degree", C.c_int64), ("limit", C.c_int64), ("alpha", C.c_double), ("cache_path", C.c_char_p)]
+
+    lib.wann_index_create.restype = C.c_void_p
+    lib.wann_index_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                      C.POINTER(BP), C.c_int, C.c_int]
+    lib.wann_batch_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(QP), C.c_void_p, C.c_void_p]
+    lib.wann_batch_search_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(QP), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.wann_gather_layout.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.wann_num_replicas.argtypes = [C.c_void_p]
+    lib.wann_index_destroy.argtypes = [C.c_void_p]
+    lib.wann_last_error.restype = C.c_char_p
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    n, d, nq, k = 6000, 32, 333, 10
+    g = sift_like(n, d, 41)
+    X, Q = np.ascontiguousarray(g(n)), np.ascontiguousarray(g(nq))
+    labels = distinct_labels(n, 9)
+    bp = BP(24, 48, 1.0, (str(tmp_path) + "/").encode())
+    h = lib.wann_index_create(3, 0, 0, X.ctypes.data, n, d, labels.ctypes.data, 400, 2.0, 0.5, C.byref(bp), 0, 0)
+    assert h, lib.wann_last_error()
+    try:
+        G = lib.wann_num_replicas(h)
+        for p in (-2, -6):
+            W32 = np.ascontiguousarray(windows(labels, nq, p, seed=5).astype(np.float32))
+            qp = QP(k, 20, 1.35, 10**7, 10**4, 2, 10000, 0, 0.0, 0)
+            ids = np.zeros((nq, k), dtype=np.uint32)
+            dists = np.zeros((nq, k), dtype=np.float32)
+            assert lib.wann_batch_search(h, Q.ctypes.data, W32.ctypes.data, nq, b"optimized_postfilter", C.byref(qp), ids.ctypes.data, dists.ctypes.data) == 0
+            planes = (C.c_void_p * G)()
+            cap = C.c_int64(0)
+            rc = lib.wann_batch_search_allgather(h, Q.ctypes.data, W32.ctypes.data, nq, b"optimized_postfilter", C.byref(qp), planes, C.byref(cap))
+            assert rc == 0, lib.wann_last_error()
+            assert cap.value == (nq + G - 1) // G
+            for r in range(G):  # every replica's device holds every shard's planes
+                host = np.zeros((G, 2, cap.value, k), dtype=np.int32)
+                assert hip.hipMemcpy(host.ctypes.data, planes[r], host.nbytes, 2) == 0
+                for s_ in range(G):
+                    lo, cnt = C.c_int64(0), C.c_int64(0)
+                    assert lib.wann_gather_layout(nq, G, s_, C.byref(lo), C.byref(cnt), None) == 0
+                    assert np.array_equal(host[s_, 0, :cnt.value].view(np.uint32), ids[lo.value:lo.value + cnt.value])
+                    assert np.array_equal(host[s_, 1, :cnt.value].view(np.float32), dists[lo.value:lo.value + cnt.value])
+                    assert (host[s_, 0, cnt.value:] == 0).all() and (host[s_, 1, cnt.value:].view(np.float32) == np.finfo(np.float32).max).all()
+    finally:
+        lib.wann_index_destroy(h)
+
+
 # ------------------------------------------------------------------------------------------
 # dense prefilter path (queries sharing a window -> MFMA GEMM + exact re-rank), adversarial-style data
 # (generate_datasets/generate_advserial_dataset.py:8-69: clusters, labels c - 0.5 + U(0,1), one window per cluster)

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define WANN_ABI_VERSION 4
-#define WANN_MAX_DEGREE 64
+#define WANN_MAX_DEGREE 128
 
 enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP = 3, WANN_ERR_IO = 4,
        WANN_ERR_UNSUPPORTED = 5 };
@@ -68,10 +68,12 @@ typedef struct {
 } wann_query_params;
 
 typedef struct {
-  int64_t max_degree;     /* R; at most 64 (WANN_MAX_DEGREE): one adjacency row is one 64-lane load and one pass of the seen
-                           * filter per hop.  The reference accepts any R (types.h:77-112, graph.h:115-124); a larger one is
-                           * refused with WANN_ERR_UNSUPPORTED, never truncated.  Every shipped configuration of the reference's
-                           * driver uses R = 64 (run_our_method.py:28). */
+  int64_t max_degree;     /* R; at most 128 (WANN_MAX_DEGREE).  Up to 64 an adjacency row is one 64-lane load and one pass of the seen
+                           * filter per hop (every kernel).  64 < R <= 128 (the reference accepts any R: types.h:77-112,
+                           * graph.h:115-124,198): rows of up to 128 ids are worked in two halves per hop by the general core of the
+                           * one-wave kernel -- same rows as the reference, lower throughput -- and such graphs are built by the host
+                           * builder.  A larger R is refused with WANN_ERR_UNSUPPORTED, never truncated.  Every shipped configuration of
+                           * the reference's driver uses R = 64 (run_our_method.py:28). */
   int64_t limit;          /* L (build beam) */
   double alpha;
   const char *cache_path; /* graph cache prefix, "" / NULL = none (postfilter_vamana.h:54-78,126-132) */

@@ -363,12 +363,17 @@ void beam_search(const SearchArgs &A, SearchOut &out) {
     }
     frontier.assign(merged.begin(), merged.begin() + m);
 
-    // first frontier entry not in visited (set_difference, :175-178)
+    // first frontier entry not in visited (std::set_difference, :175-178).  MULTISET semantics: an equal pair consumes ONE
+    // element of each side, so a frontier that holds two copies of an entry (a row listed the node twice and the lossy filter
+    // let both through) against a visited list that holds one still has a copy "unvisited" -- the reference visits it again.
     have_next = false;
     size_t vi = 0;
     for (size_t fi = 0; fi < frontier.size(); fi++) {
       while (vi < visited.size() && pid_less(visited[vi], frontier[fi])) vi++;
-      if (vi < visited.size() && !pid_less(frontier[fi], visited[vi])) continue;  // equal
+      if (vi < visited.size() && !pid_less(frontier[fi], visited[vi])) {  // equal: both advance
+        vi++;
+        continue;
+      }
       next = frontier[fi];
       have_next = true;
       break;

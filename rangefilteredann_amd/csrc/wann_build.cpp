@@ -327,7 +327,7 @@ void build_search(const BuildView &V, const HostGraph &G, int32_t index, Scratch
     const int64_t deg = std::min<int64_t>(row[0], G.maxdeg);
     const float cutoff = ((int64_t)S.front.size() < B) ? (float)INT_MAX : key_dist(S.front.back());
     S.cand.clear();
-    int32_t kept[64 + 1];
+    int32_t kept[128 + 1];  // (max_degree <= 128: wann.h WANN_MAX_DEGREE)
     int nk = 0;
     for (int64_t i = 0; i < deg; i++) {
       const int32_t a = row[1 + i];
@@ -749,7 +749,7 @@ void build_host_index(HostIndex &H, const void *points, const float *labels, int
       throw std::runtime_error("unknown index kind");
   }
   if (!H.vamana_leaves) return;
-  if (s.R > 64) throw std::runtime_error("max_degree > 64 is not supported by the gfx950 search kernel");
+  if (s.R > 128) throw std::runtime_error("max_degree > 128 is not supported by the gfx950 search kernels (WANN_MAX_DEGREE)");
 
   // graphs: load what the cache holds, build the rest in lock-step, publish to the cache
   const bool sharded = nshards > 0;

@@ -346,6 +346,9 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   RoundCfg rc{};
   const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
   if (cap_bytes > base_pool) big_lds = true;
+  // Rows of more than 64 neighbours (64 < R <= 128) are worked in two halves by the first-generation general core only: every
+  // search of such an index runs in the one-wave kernel that holds it (k_search<., 2>), eight workgroups per CU.
+  if (I.view.rs > 64) big_lds = legacy = true;
   const int wpb = big_lds ? 1 : kWavesPerBlock;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
   if (big_lds && !legacy && cap_bytes + 4096 + kScoreBoxBytes > 150 * 1024 - common) legacy = true;
@@ -506,7 +509,8 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.host().spec.split_factor <= 4);
   const int maxt = single ? 1 : 96;
   const Tuning &T = I.tune;
-  const bool spec = I.host().vamana_leaves && T.spec;
+  // (wide rows, R > 64: plain in-kernel doubling in the one-wave kernel, no speculative levels / companion launch)
+  const bool spec = I.host().vamana_leaves && T.spec && I.view.rs <= 64;
   const int64_t sub_slots = spec ? std::min<int64_t>(nq * (int64_t)maxt * 4 + 1024, (int64_t)1 << 26) : 0;
   W.ensure(nq, k, maxt, sub_slots);
   if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
@@ -646,7 +650,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     sa.mult = (int32_t)std::min<int64_t>(qp.final_beam_multiply, INT32_MAX);
     sa.max_beam = (int32_t)qp.postfiltering_max_beam;
     sa.pool_bytes = kSearchPoolBytes;
-    sa.force_general = T.force_general ? 1 : 0;
+    sa.force_general = (T.force_general || I.view.rs > 64) ? 1 : 0;  // (wide rows: the register-resident cores take 64 neighbours)
     sa.search_prio = T.search_prio;  // dev knob
     sa.out_key = W.out_key.p;
     sa.out_cnt = W.out_cnt.p;
@@ -670,7 +674,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     int64_t max_part = 1;
     for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
-    sa.old_general = T.old_general ? 1 : 0;
+    sa.old_general = (T.old_general || I.view.rs > 64) ? 1 : 0;
     // (idle pollers look for chains that will outgrow their speculated levels: on unless WANN_SCAN=0)
     const bool scan_on = spec && T.scan && T.lookahead;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0,
@@ -1006,7 +1010,9 @@ void build_pending(wann_index &I, std::vector<HostPart *> &pending) {
     }
   // WANN_HOST_BUILD=1 (tests: the host builder as a cross-check) is the only way onto the host builder; a
   // visited list that outgrows its LDS buffer restarts the build ON THE GPU with a larger buffer.
-  if (getenv("WANN_HOST_BUILD") != nullptr) {
+  // (R > 64: the GPU builder's rows are one wave wide -- such graphs are built by the host builder, byte-identical to the
+  // reference's like the GPU builder's)
+  if (getenv("WANN_HOST_BUILD") != nullptr || s.R > 64) {
     build_pending_on_host(H, pending);
     for (auto &t : targets) upload_part_rows(I, *t.part, I.parts[t.part_index]);
   } else {
@@ -1769,7 +1775,8 @@ struct RawGraph {
     const bool with_cut = cut_k > 0;
     if (I.tune.hooks_live) I.tune = Tuning::from_env();  // (tests flip the core switches between calls on one VamanaIndex)
     const Tuning &T = I.tune;
-    const bool old_general = T.old_general || with_cut, force_general = T.force_general || with_cut;
+    const bool wide = I.view.rs > 64;
+    const bool old_general = T.old_general || with_cut || wide, force_general = T.force_general || with_cut || wide;
     // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
     RoundCfg rc = config_for(I, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general);
     SearchArgs sa{};
@@ -1865,7 +1872,7 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, 
                          int64_t *out_dist_cmps, int device) {
   if (usable_devices() <= device || device < 0)
     return fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
-  if (maxdeg > 64) return fail(WANN_ERR_UNSUPPORTED, "max_degree > 64 is not supported");
+  if (maxdeg > WANN_MAX_DEGREE) return fail(WANN_ERR_UNSUPPORTED, "max_degree > 128 is not supported");
   try {
     RawGraph G;
     G.load(device, metric, points, n, d, graph_rows, maxdeg, subset_start, subset_n);
@@ -1930,7 +1937,7 @@ wann_vamana *wann_vamana_open(int metric, int dtype, const char *data_path, cons
     HostGraph g;
     if (!graph_file_load(graph_path, g)) throw std::runtime_error(std::string("cannot read graph file ") + graph_path);
     if (g.n != n) throw std::runtime_error("graph file and point file disagree on the number of points");
-    if (g.maxdeg > 64) throw std::runtime_error("max_degree > 64 is not supported");
+    if (g.maxdeg > WANN_MAX_DEGREE) throw std::runtime_error("max_degree > 128 is not supported");
     V->G.load(device, metric, raw.data(), n, d, g.rows.data(), g.maxdeg, 0, n, dtype);
     return V.release();
   } catch (HipError &e) {

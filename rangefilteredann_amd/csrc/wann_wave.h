@@ -499,9 +499,12 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
 // cand_key: 64 u64 of per-wave LDS scratch.
 // --------------------------------------------------------------------------------------------
 // PRESORTED: the candidates sit in lanes 0..c-1 in ascending key order already (no ranking pass).
+// prev_key / prev_mask (rows of more than 64 neighbours are worked in two halves, wave_beam_search): the passing candidates of the
+// row's FIRST half, in their lanes -- a copy of one of them among this call's candidates counts as a further copy of the same
+// std::set_union operand (the reference unions the whole row's candidates at once).
 template <typename BeamPtr, bool DEDUP = true, bool PRESORTED = false>
 __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass, u64 key,
-                                          u64 *cand_key, int *first_pos) {
+                                          u64 *cand_key, int *first_pos, u64 prev_key = 0ull, u64 prev_mask = 0ull) {
   const int lane = lane_id();
   *first_pos = m;
   u64 smask = ballot64(pass);
@@ -562,8 +565,11 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
   // arise when a row lists a node twice -- the reference's builder can append the start point
   // twice -- and the lossy filter lets both through.)
   bool dup = false;
+  int prior = 0;  // copies of this key among the first half's candidates (wave-uniform loop; nearly always empty)
+  if (DEDUP)
+    for (u64 mm = prev_mask; mm; mm &= mm - 1) prior += (mine && (rdlane64(prev_key, ctz64(mm)) | 1ull) == (ck | 1ull)) ? 1 : 0;
   if (DEDUP && mine) {
-    int j = 0, bx = 0;
+    int j = prior, bx = 0;
     for (int l = lane - 1; l >= 0 && cand_key[l] == ck; l--) j++;
     while (pos + bx < m && ((beam[pos + bx] | 1ull) == (ck | 1ull))) bx++;
     dup = j < bx;
@@ -793,10 +799,23 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     }
     nvis++;
 
+    // ---- the cutoff of this hop (beamSearch.h:135-137): fixed BEFORE the row's candidates enter the beam
+    float cutoff = 2147483648.0f;  // (float)INT_MAX
+    if (m >= B) cutoff = funkey((uint32_t)(beam_ld(m - 1) >> 32));
+    // A row of more than 64 neighbours (64 < R <= 128, graph.h:115-124 takes any R) is worked in two halves of 64 lanes: the
+    // lossy filter is sequential over the row's elements anyway (the second half sees the table the first left), both halves
+    // are scored against the hop's cutoff, and the union of (beam + first half, truncated) with the second half keeps the
+    // same B smallest entries as one union of everything; std::set_union's multiset rule needs the first half's candidates
+    // when the second half's are merged (wave_merge: prev_key / prev_mask).
+    const int nhalf = (ix.rs + 63) >> 6;
+    int p0 = m;
+    u64 key_h0 = 0ull, mask_h0 = 0ull;
+    for (int half = 0; half < nhalf; half++) {
     // ---- adjacency row, coalesced (graph.h:198); -1 = unused slot
+    const int slot = 64 * half + lane;
     int a = -1;
-    if (lane < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + lane];
-    bool valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
+    if (slot < ix.rs) a = ix.graph[(part.row_base + cur) * (int64_t)ix.rs + slot];
+    bool valid = (a >= 0) && (slot < degree_limit) && ((int64_t)a != qid);
     if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WANN_PHASE(0);  // row fetch
 
@@ -853,8 +872,6 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     WANN_PHASE(1);  // seen-filter
 
     // ---- score the kept neighbours (beamSearch.h:135-145)
-    float cutoff = 2147483648.0f;  // (float)INT_MAX
-    if (m >= B) cutoff = funkey((uint32_t)(beam_ld(m - 1) >> 32));
     float dist = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, nk, row_off);
     int cid = (lane < nk) ? L.cand_id[lane] : 0;
     WAVE_SYNC();
@@ -864,9 +881,13 @@ __device__ __forceinline__ void wave_beam_search(const IndexView &ix, const Part
     WANN_PHASE(2);  // vector fetch + distances
 
     // ---- sort + set_union + truncate (beamSearch.h:148-157)
-    int p0;
-    if (BEAM_LDS) m = wave_merge(L.lbeam, m, B, pass, key, L.cand_key, &p0);
-    else m = wave_merge(gbeam, m, B, pass, key, L.cand_key, &p0);
+    int p0h;
+    if (BEAM_LDS) m = wave_merge(L.lbeam, m, B, pass, key, L.cand_key, &p0h, key_h0, mask_h0);
+    else m = wave_merge(gbeam, m, B, pass, key, L.cand_key, &p0h, key_h0, mask_h0);
+    p0 = p0h < p0 ? p0h : p0;
+    key_h0 = key;
+    mask_h0 = ballot64(pass);
+    }  // (the row's halves)
     // ---- beamSearch.h:159-167: with a k (unfiltered VamanaIndex queries) and a metric distance, entries beyond
     //      cut * (distance of entry k) leave: upper_bound of (id 0, that distance) under (dist, id) order
     if (METRIC == 0 && cut_k > 0 && m > cut_k) {

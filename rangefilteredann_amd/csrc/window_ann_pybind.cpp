@@ -215,6 +215,7 @@ class Index {
     if (wann_partition_range(h_, level, idx, &s, &e)) raise_last("partition_range");
     return {s, e};
   }
+  int64_t max_degree() const { return wann_max_degree(h_); }
   py::array_t<int32_t> partition_graph(int64_t level, int64_t idx, int64_t max_degree) const {
     auto [s, e] = partition_range(level, idx);
     py::array_t<int32_t> rows({(size_t)(e - s), (size_t)(max_degree + 1)});
@@ -249,6 +250,7 @@ static void common_defs(py::class_<C> &c) {
       .def("partition_range", &C::partition_range)
       .def("partition_graph", &C::partition_graph, "level"_a, "idx"_a, "max_degree"_a)
       .def("device_bytes", &C::device_bytes)
+      .def("max_degree", &C::max_degree)
       .def("num_replicas", &C::num_replicas)
       .def("num_points", &C::num_points)
       .def("dim", &C::dim);

@@ -30,13 +30,13 @@ def qp(ref, beam, mult, max_beam=10000, ratio=None):
     return ref.QueryParams(K, beam, 1.35, 10_000_000, 10_000, mult, max_beam, ratio, False)
 
 
-def make(name, metric, X, Q, labels, R, L, cutoff, elem="Float"):
+def make(name, metric, X, Q, labels, R, L, cutoff, elem="Float", alpha=1.0):
     ref = orc.load_reference(prefer=("native",))
     assert ref is not None, "build the reference first: make -C oracle ref REF_MARCH=native"
     sfx = elem + ("Mips" if metric == "mips" else "Euclidian")
     nq = Q.shape[0]
     tmp = tempfile.mkdtemp(prefix="golden_")
-    out = {"X": X, "Q": Q, "labels": labels, "meta": np.array([R, L, cutoff, K], dtype=np.int64)}
+    out = {"X": X, "Q": Q, "labels": labels, "meta": np.array([R, L, cutoff, K, int(round(alpha * 1000))], dtype=np.int64)}
     W = {p: windows(labels, nq, p, seed=100 + p) for p in FRACTIONS}
     # one window entirely outside the label span and one of width zero, in a separate batch
     Wedge = np.array([[5.0, 6.0], [-3.0, -2.0], [labels[7], labels[7]], [0.25, 0.2501]] * (nq // 4), dtype=np.float64)
@@ -56,7 +56,7 @@ def make(name, metric, X, Q, labels, R, L, cutoff, elem="Float"):
         os.makedirs(cdir)
         labkw = "filters" if kind == "PostfilterVamanaIndex" else "filter_values"
         with quiet_stdout():
-            idx = getattr(ref, kind + sfx)(X, **{labkw: labels}, build_params=ref.BuildParams(R, L, 1.0, cdir), **kw)
+            idx = getattr(ref, kind + sfx)(X, **{labkw: labels}, build_params=ref.BuildParams(R, L, alpha, cdir), **kw)
         for f in sorted(os.listdir(cdir)):
             files[f"{kind}/{f}"] = np.frombuffer(open(cdir + f, "rb").read(), dtype=np.uint8)
         methods = TREE_METHODS if kind.endswith("RangeFilterTreeIndex") else [""]
@@ -112,3 +112,8 @@ if __name__ == "__main__":
     n, d, nq = 640, 512, 16
     g = sift_like(n, d, 2468)
     make("u8_l2_d512", "Euclidian", g(n).astype(np.uint8), g(nq).astype(np.uint8), distinct_labels(n, 11), R=16, L=32, cutoff=200, elem="UInt8")
+    # max_degree 96 (graph.h:115-124 takes any R): with alpha = 1.35 a quarter of the rows of the large partitions list more than
+    # 64 neighbours -- the kernels work such rows in two halves
+    n, d, nq = 3000, 32, 48
+    g = sift_like(n, d, 777)
+    make("sift_l2_r96", "Euclidian", g(n), g(nq), distinct_labels(n, 21), R=96, L=192, cutoff=400, alpha=1.35)

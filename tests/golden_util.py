@@ -7,7 +7,8 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FIXTURES = {"sift_l2": "FloatEuclidian", "unit_mips": "FloatMips", "u8_l2": "UInt8Euclidian", "i8_mips": "Int8Mips",
-            "u8_l2_d512": "UInt8Euclidian"}  # (512 bytes per row: beyond what float32 accumulation represents exactly)
+            "u8_l2_d512": "UInt8Euclidian",  # (512 bytes per row: beyond what float32 accumulation represents exactly)
+            "sift_l2_r96": "FloatEuclidian"}  # (max_degree 96, alpha 1.35: rows of more than 64 neighbours)
 KINDS = {
     "VamanaRangeFilterTreeIndex": dict(split_factor=2),
     "SuperOptimizedPostfilterTreeIndex": dict(split_factor=2, shift_factor=0.5),
@@ -45,14 +46,15 @@ def unpack_cache(graphs, kind, dst):
 
 def build_index(mod, name, kind, tmpdir):
     data, graphs = load(name)
-    R, L, cutoff, _ = [int(x) for x in data["meta"]]
+    R, L, cutoff = [int(x) for x in data["meta"][:3]]
+    alpha = float(data["meta"][4]) / 1000.0 if len(data["meta"]) > 4 else 1.0
     cache = unpack_cache(graphs, kind, os.path.join(str(tmpdir), name, kind))
     kw = dict(KINDS[kind])
     if kind.endswith("TreeIndex"):
         kw["cutoff"] = cutoff
     labkw = "filters" if kind == "PostfilterVamanaIndex" else "filter_values"
     cls = getattr(mod, kind + FIXTURES[name])
-    idx = cls(data["X"], **{labkw: data["labels"]}, build_params=mod.BuildParams(R, L, 1.0, cache), **kw)
+    idx = cls(data["X"], **{labkw: data["labels"]}, build_params=mod.BuildParams(R, L, alpha, cache), **kw)
     return idx, data
 
 

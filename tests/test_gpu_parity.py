@@ -93,6 +93,80 @@ def test_raw_beam_search_core_variants(oracle, wa, gpu, monkeypatch, env, metric
             assert int(hops[i]) == len(vi) and int(cmps[i]) == dc, (beam, i, hops[i], len(vi), cmps[i], dc)
 
 
+@pytest.mark.parametrize("metric,gen,d,R", [(0, sift_like, 64, 96), (1, unit_mixture, 100, 128), (0, unit_mixture, 40, 80)])
+def test_raw_beam_search_on_wide_rows(oracle, wa, gpu, metric, gen, d, R):
+    """64 < max_degree <= 128 (graph.h:115-124 takes any R): rows of up to 128 neighbours, worked in two halves per hop, against
+    the oracle -- ids, distances, hops, dist_cmps at small and large beams, degree limits that cut inside the second half, and
+    rows that list a node in BOTH halves with a node of the same filter slot in between (the reference's multiset union then
+    keeps two copies: the second half's union counts the first half's candidates)."""
+    n, nq, L = 4000, 48, 2 * R
+    g = gen(n, d, 31)
+    X, Q = g(n), g(nq)
+    Xp = oracle.pad_rows(X)
+    start, sn = 200, 3500
+    rows = oracle.vamana_build(Xp, d, metric, start, sn, R, L, 1.35).copy()
+    rng = np.random.default_rng(5)
+    # (inner-product builds prune hard: a third of the rows get further, random neighbours up to 65 .. R -- the search does not
+    # care where a row came from)
+    for r in rng.choice(sn, sn // 3, replace=False):
+        have = set(int(x) for x in rows[r, 1:1 + rows[r, 0]])
+        want = int(rng.integers(65, R + 1))
+        while len(have) < want:
+            have.add(int(rng.integers(0, sn)))
+        lst = list(rows[r, 1:1 + rows[r, 0]]) + sorted(have - set(int(x) for x in rows[r, 1:1 + rows[r, 0]]))
+        rows[r, 0] = len(lst)
+        rows[r, 1:1 + len(lst)] = lst
+    deg = rows[:, 0]
+    assert (deg > 64).sum() > 500 and deg.max() <= R
+    # rows (.., 0 at slot 3, .., b, 0 at slots 70, 71) with hash(b) = hash(0) in the 2^10-slot filter: node 0 passes the filter twice
+    same = [b for b in range(1, sn) if (_hash64_2(b) ^ _hash64_2(0)) & 1023 == 0]
+    wide = np.flatnonzero(deg > 72)
+    for r in rng.choice(wide, min(200, len(wide)), replace=False):
+        rows[r, 1 + 3] = 0
+        rows[r, 1 + 70] = same[int(r) % len(same)]
+        rows[r, 1 + 71] = 0
+    qids = np.arange(nq, dtype=np.int64) + 10**6
+    qids[::4] = np.arange(0, nq, 4) + 100  # (some queries carry the id of a node: the self-skip quirk)
+    for beam, limit, dl in ((10, 10**7, 10**4), (40, 10**7, 10**4), (100, 10**7, 10**4), (160, 10**7, 10**4), (700, 10**7, 10**4),
+                            (2500, 10**7, 10**4), (40, 10**7, 70), (100, 25, 100)):
+        ids, dists, sizes, hops, cmps = wa.raw_beam_search(metric, X, rows, start, Q, qids, beam, limit, dl)
+        for i in range(nq):
+            oi, od, vi, vd, dc = oracle.beam_search(rows, Xp, d, metric, start, Q[i], int(qids[i]), beam, limit=limit, degree_limit=dl)
+            m = int(sizes[i])
+            assert m == len(oi), (beam, i, m, len(oi))
+            assert np.array_equal(ids[i, :m], oi), (beam, dl, i)
+            assert np.array_equal(dists[i, :m], od), (beam, i)
+            assert int(hops[i]) == len(vi) and int(cmps[i]) == dc, (beam, i, hops[i], len(vi), cmps[i], dc)
+
+
+def test_wide_row_index_matches_oracle(oracle, wa, gpu, tmp_path):
+    """an index with max_degree 96 end to end: built by the product (the host builder: byte-identical graph files to the oracle's),
+    searched by the two-halves core in the one-wave kernel -- rows and work counters equal the oracle's; R > 128 is refused"""
+    n, d, nq = 5000, 48, 300
+    g = sift_like(n, d, 61)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 23)
+    c1, c2 = str(tmp_path / "a") + "/", str(tmp_path / "b") + "/"
+    os.makedirs(c1), os.makedirs(c2)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=600, split_factor=2, build_params=wa.BuildParams(96, 192, 1.35, c1))
+    oi = oracle.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=600, split_factor=2, build_params=oracle.BuildParams(96, 192, 1.35, c2))
+    for f in sorted(os.listdir(c2)):
+        assert open(c1 + f, "rb").read() == open(c2 + f, "rb").read(), f
+    assert idx.max_degree() == 96
+    for p, method, beam, mult in ((-2, "optimized_postfilter", 20, 2), (-5, "optimized_postfilter", 10, 1), (-7, "optimized_postfilter", 10, 2),
+                                  (-4, "fenwick", 20, 1), (-3, "three_split", 20, 2)):
+        W = windows(labels, nq, p, 70 + p)
+        ids, dists = idx.batch_search(Q, W.astype(np.float32), nq, method, _qp(wa, beam, mult))
+        eids, edists = oi.batch_search(Q, W, nq, method, _qp(oracle, beam, mult))
+        ok, why = gu.same_rows(eids, edists, ids, dists, method != "optimized_postfilter", gu.RowContext(X, labels, Q, W, "l2"))
+        assert ok, (p, method, why)
+        c = idx.counters()
+        assert (c["beam_searches"], c["hops"]) == (oi.last_counters["searches"], oi.last_counters["hops"]), (p, method)
+        assert c["dist_cmps"] + c["brute_rows"] == oi.last_counters["dist_cmps"], (p, method)  # (the oracle counts scanned rows there too)
+    with pytest.raises(RuntimeError):
+        wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=600, split_factor=2, build_params=wa.BuildParams(129, 192, 1.0, ""))
+
+
 def test_raw_beam_search_limits(oracle, wa, gpu):
     n, d, nq = 1500, 32, 40
     g = sift_like(n, d, 5)

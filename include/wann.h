@@ -64,7 +64,8 @@ typedef struct {
   int64_t postfiltering_max_beam;
   int32_t has_min_query_to_bucket_ratio; /* std::optional<float>::has_value() */
   float min_query_to_bucket_ratio;
-  int32_t verbose;                /* accepted, ignored                   */
+  int32_t verbose;                /* the doubling loop of every search is dumped to stdout in the reference's words
+                                     (postfilter_vamana.h:155-185,230); such a call runs in the one-wave legacy kernel */
 } wann_query_params;
 
 typedef struct {

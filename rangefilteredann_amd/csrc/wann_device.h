@@ -211,6 +211,12 @@ struct SearchArgs {
   const int32_t *scan_list, *scan_count;  // idle pollers scan these speculating tasks (k_route's list) for ones that will
   int32_t scan_min_top;                   // need the level after their highest one (highest beam >= scan_min_top); null = no scan
   int32_t la_found_max;  // a chain asks for a look-ahead when its last level found fewer in-window entries than this (0.4 k)
+  // QueryParams::verbose (postfilter_vamana.h:155-185,230): one record per search of a task's doubling loop -- beam << 42 |
+  // unfiltered beam size << 21 | in-window entries of the WHOLE final beam -- in vlog[task * vlog_cap + i], i < vlog_n[task]
+  // (one-wave legacy kernel only: the host routes a verbose call there, without speculative levels); null = off
+  unsigned long long *vlog;
+  int32_t *vlog_n;
+  int32_t vlog_cap;
 };
 
 struct OrderArgs {  // k_order_heavy: `in` (count entries: task slots) reordered into `out`

@@ -85,6 +85,8 @@ struct Workspace {
   DevBuf<Counters> ctr;
   DevBuf<float> q_stage, r_stage, dist_stage;
   DevBuf<uint32_t> id_stage;
+  DevBuf<unsigned long long> vlog;  // QueryParams::verbose: per-task records of the doubling loop (SearchArgs::vlog)
+  DevBuf<int32_t> vlog_n;
   DevBuf<int32_t> gat_send, gat_recv;  // wann_batch_search_allgather: this replica's [2][cap][k] planes / everybody's [world][2][cap][k]
   int32_t big_stride = 0;
   int32_t *h_ints = nullptr;  // pinned
@@ -509,8 +511,12 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.host().spec.split_factor <= 4);
   const int maxt = single ? 1 : 96;
   const Tuning &T = I.tune;
+  // QueryParams::verbose (postfilter_vamana.h:155-185,230): the doubling loop of every (query, partition) search is dumped to
+  // stdout in the reference's words after the batch -- a debugging aid: such a call runs plain sequential doubling in the
+  // one-wave legacy kernel, which records every search
+  const bool verbose_call = qp.verbose != 0 && I.host().vamana_leaves;
   // (wide rows, R > 64: plain in-kernel doubling in the one-wave kernel, no speculative levels / companion launch)
-  const bool spec = I.host().vamana_leaves && T.spec && I.view.rs <= 64;
+  const bool spec = I.host().vamana_leaves && T.spec && I.view.rs <= 64 && !verbose_call;
   const int64_t sub_slots = spec ? std::min<int64_t>(nq * (int64_t)maxt * 4 + 1024, (int64_t)1 << 26) : 0;
   W.ensure(nq, k, maxt, sub_slots);
   if (spec) HIP_CHECK(hipMemsetAsync(W.par_done.p, 0, ((size_t)nq * maxt) * sizeof(int32_t), st));
@@ -650,7 +656,17 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     sa.mult = (int32_t)std::min<int64_t>(qp.final_beam_multiply, INT32_MAX);
     sa.max_beam = (int32_t)qp.postfiltering_max_beam;
     sa.pool_bytes = kSearchPoolBytes;
-    sa.force_general = (T.force_general || I.view.rs > 64) ? 1 : 0;  // (wide rows: the register-resident cores take 64 neighbours)
+    sa.force_general = (T.force_general || I.view.rs > 64 || verbose_call) ? 1 : 0;  // (wide rows: the register-resident cores take 64 neighbours)
+    constexpr int kVlogCap = 24;
+    if (verbose_call) {
+      const size_t nt = (size_t)nq * maxt;
+      W.vlog.ensure(nt * kVlogCap);
+      W.vlog_n.ensure(nt);
+      HIP_CHECK(hipMemsetAsync(W.vlog_n.p, 0, nt * sizeof(int32_t), st));
+      sa.vlog = W.vlog.p;
+      sa.vlog_n = W.vlog_n.p;
+      sa.vlog_cap = kVlogCap;
+    }
     sa.search_prio = T.search_prio;  // dev knob
     sa.out_key = W.out_key.p;
     sa.out_cnt = W.out_cnt.p;
@@ -674,12 +690,12 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     int64_t max_part = 1;
     for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
-    sa.old_general = (T.old_general || I.view.rs > 64) ? 1 : 0;
+    sa.old_general = (T.old_general || I.view.rs > 64 || verbose_call) ? 1 : 0;
     // (idle pollers look for chains that will outgrow their speculated levels: on unless WANN_SCAN=0)
     const bool scan_on = spec && T.scan && T.lookahead;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0,
                       int base_pool = kSearchPoolBytes) {
-      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds, a.force_general != 0, a.old_general != 0, base_pool);
+      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds || verbose_call, a.force_general != 0, a.old_general != 0, base_pool);
       big_lds = rc.big_lds;
       a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
       a.helper = (rc.lc.big == 1 && T.helper) ? kHelpers : 0;
@@ -951,6 +967,54 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   HIP_CHECK(hipEventRecord(W.ev[1], st));
   HIP_CHECK(hipStreamSynchronize(st));
 
+  if (verbose_call && W.vlog.p) {
+    // the reference's dump (postfilter_vamana.h:155-185 + :230), per query and partition search, in query order
+    const size_t nt = (size_t)nq * maxt;
+    constexpr int cap_v = 24;
+    std::vector<Task> ht(nt);
+    std::vector<int32_t> hq((size_t)nq), hn(nt);
+    std::vector<unsigned long long> hv(nt * cap_v);
+    HIP_CHECK(hipMemcpy(ht.data(), W.tasks.p, nt * sizeof(Task), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hq.data(), W.qtask_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hn.data(), W.vlog_n.p, nt * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hv.data(), W.vlog.p, hv.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t q = 0; q < nq; q++)
+      for (int i = 0; i < hq[(size_t)q]; i++) {
+        const size_t ti = (size_t)q * maxt + i;
+        const Task &t = ht[ti];
+        if (t.mode != T_GRAPH) continue;
+        const long long mult = (t.flags & 2) ? 1 : (long long)qp.final_beam_multiply;
+        printf("Starting optimized postfiltering, beam size = %lld, k = %lld, final multiply = %lld, n = %d\n", (long long)qp.beam_width,
+               (long long)qp.k, mult, I.parts[(size_t)t.part].n);
+        long long beam = qp.beam_width, frontier = 0;
+        int e = 0;
+        const int ne = std::min(hn[ti], cap_v);
+        auto rec = [&](int j, long long &b_, long long &m_, long long &f_) {
+          const unsigned long long v = hv[ti * cap_v + (size_t)j];
+          b_ = (long long)(v >> 42);
+          m_ = (long long)((v >> 21) & 0x1fffff);
+          f_ = (long long)(v & 0x1fffff);
+        };
+        while (frontier < qp.k && beam < qp.postfiltering_max_beam && e < ne) {  // :161-172
+          long long b_, m_, f_;
+          rec(e++, b_, m_, f_);
+          printf("Unfiltered return = %lld\n", m_);
+          frontier = f_;
+          printf("Finished a double, frontier size = %lld, beam size = %lld\n", frontier, beam);
+          if (frontier < qp.k) beam *= 2;
+        }
+        const long long fb = std::min<long long>(beam * mult, qp.postfiltering_max_beam);
+        if (fb > beam && e < ne) {  // :173-181
+          long long b_, m_, f_;
+          rec(e++, b_, m_, f_);
+          printf("Unfiltered return = %lld\n", m_);
+          frontier = f_;
+          beam = fb;
+        }
+        printf("Final frontier size = %lld, final beam size %lld\n", frontier, beam);
+      }
+    fflush(stdout);
+  }
   float ms = 0.f;
   HIP_CHECK(hipEventElapsedTime(&ms, W.ev[0], W.ev[1]));
   last.device_ms = ms;

@@ -648,6 +648,30 @@ def test_mid_fraction_machinery_matches_oracle(oracle, wa, gpu, tmp_path, monkey
     print(variant, tot)
 
 
+def test_final_research_of_a_resolved_chain_is_never_moot(oracle, wa, gpu, tmp_path):
+    """final_beam_multiply > 1: the wave that resolves a doubling chain goes on AS THE PARENT and searches the final beam.  Its
+    sub-task's moot state (a lower level of the same parent succeeded meanwhile) must not follow it there -- it once did, and a
+    third of the runs of this batch lost a row's final search (timing dependent, hence the repetitions).  Rows and work counters
+    against the oracle, every time."""
+    n, d, nq = 150000, 64, 1500
+    g = sift_like(n, d, 14)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 16)
+    cache = str(tmp_path) + "/"
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, cache))
+    ref = oracle.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=oracle.BuildParams(24, 64, 1.0, cache))
+    for p, beam, mult, reps in [(-8, 20, 3, 12), (-9, 40, 2, 6)]:
+        W = windows(labels, nq, p, seed=5)
+        eids, edists = ref.batch_search(Q, W, nq, "optimized_postfilter", _qp(oracle, beam, mult))
+        oc = ref.last_counters
+        for rep in range(reps):
+            ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
+            c = idx.counters()
+            assert np.array_equal(dists, edists) and np.array_equal(ids, eids), (p, beam, mult, rep, np.nonzero((ids != eids).any(1))[0][:10])
+            assert (c["beam_searches"], c["hops"], c["dist_cmps"]) == (oc["searches"], oc["hops"], oc["dist_cmps"]), (p, beam, mult, rep, c, oc)
+        assert c["spec_searches"] > 0
+
+
 def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
     """A saturated launch ends with its few longest doubling chains.  With enough tasks a handful of pollers (a CU each) take
     over chains that reach their third level; which wave runs a search must not change a row or a work counter."""

@@ -14,5 +14,5 @@ done
 for v in tree $(ls -d tools/_scratch/ab* 2>/dev/null); do
   if [ $v = tree ]; then L=$LD_LIBRARY_PATH; else L=$PWD/$v:$LD_LIBRARY_PATH; fi
   echo "== $v" >> $O/mid.log
-  LD_LIBRARY_PATH=$L python tools/frac_probe.py --fractions=-8,-9,-11 --settings 80,1 --reps 4 2>&1 | grep "^2\^" | cut -c1-75 >> $O/mid.log
+  LD_LIBRARY_PATH=$L python tools/frac_probe.py --fractions=-5,-6,-7,-8,-9,-10,-11 --settings 80,1 --reps 4 2>&1 | grep "^2\^" | cut -c1-75 >> $O/mid.log
 done

@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 n, d, nq = 150000, 64, 1500
 g = sift_like(n, d, 14); X, Q = g(n), g(nq); labels = distinct_labels(n, 16)
 idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, ""))
-cases = [(-9, 10, 1), (-8, 80, 1), (-9, 40, 2), (-6, 40, 1), (-10, 20, 1), (-3, 64, 1)]
+cases = [(-9, 10, 1), (-8, 80, 1), (-9, 40, 2), (-6, 40, 1), (-10, 20, 1), (-3, 64, 1), (-8, 20, 3), (-10, 10, 4), (-7, 40, 2)]
 base, reps, bad = {}, 0, 0
 t0 = time.time()
 while time.time() - t0 < budget:

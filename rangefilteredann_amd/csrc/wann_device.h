@@ -277,6 +277,8 @@ struct LaunchCfg {
 int launch_route(const RouteArgs &a, void *stream);
 int launch_order_heavy(const OrderArgs &a, void *stream);
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);
+// workgroups of that launch the runtime expects to be resident per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor); -1 on error
+int search_occupancy(const SearchArgs &a, const LaunchCfg &cfg);
 int launch_brute(const BruteArgs &a, int blocks, void *stream);
 int launch_finalize(const FinalizeArgs &a, void *stream);
 int launch_task_cost(const CostArgs &a, void *stream);

@@ -343,6 +343,8 @@ struct RoundCfg {
 // what a beam that does not fit the LDS next to the helper waves' mailbox gets.  The production one-wave kernel
 // (k_search<., 1>) always keeps its seen-filter in global memory.
 // base_pool: the four-wave kernel's per-wave pool (kSearchPoolBytes, or lean_pool_bytes() for three workgroups per CU).
+constexpr int kLdsBudget = 156 * 1024;  // of the 160 KiB per CU: what co-resident workgroups can be counted on to share (lean_pool_bytes)
+
 RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false,
                     bool legacy = false, int base_pool = kSearchPoolBytes) {
   RoundCfg rc{};
@@ -369,7 +371,7 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   // (four-wave kernel: the squared-L2 float kernel needs 232 registers: two waves per SIMD; the inner-product and byte-row
   // kernels are built for three)
   const int waves_per_cu = (I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32) ? 12 : 8;
-  int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, (160 * 1024) / per_block);
+  int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, kLdsBudget / per_block);  // (see lean_pool_bytes: the last 4 KiB do not count)
   blocks_per_cu = std::max(1, blocks_per_cu);
   if (I.tune.blocks_per_cu > 0) blocks_per_cu = std::max(1, std::min(blocks_per_cu, I.tune.blocks_per_cu));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
@@ -397,8 +399,10 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
 int lean_pool_bytes(const wann_index &I) {
   if (!(I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32)) return 0;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
-  // (a workgroup's LDS is allocated in 1 KiB steps at most: 53 KiB per workgroup, three of them in 160 KiB)
-  int pool = (53 * 1024) / kWavesPerBlock - common;
+  // 52 KiB per workgroup.  Three workgroups of 53 KiB (159 of the CU's 160 KiB) are NOT co-resident on gfx950, whatever
+  // hipOccupancyMaxActiveBlocksPerMultiprocessor says (3): a launch of 768 such workgroups ran at the speed of 512 until round 4
+  // measured it (stand-alone inner-product graph, 30 000 searches at beam 80: 6.65 ms at 53 KiB, 5.22 ms at 52.5 KiB and below).
+  int pool = (52 * 1024) / kWavesPerBlock - common;
   if (I.tune.lean_pool > 0) pool = I.tune.lean_pool;  // dev knob
   return pool >= kInKernelBeamCap * 8 + 1536 ? pool : 0;
 }
@@ -803,6 +807,10 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         HIP_CHECK(hipEventRecord(W.ev_side, side));
       }
       if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
+      if (T.verbose)
+        fprintf(stderr, "[wann launch] kind %d: %d workgroups x %d waves (%d per CU by the runtime's occupancy), pool %d B per wave, beams %ld..%ld, %ld items; companion %d (cap %d, pool %d B, pollers %d)\n",
+                rc.lc.big, rc.lc.blocks, rc.lc.waves_per_block, search_occupancy(a, rc.lc), a.pool_bytes, (long)first_beam, (long)cap, (long)items, with_big ? big_lc.blocks : 0,
+                with_big ? big.cap_inkernel : 0, with_big ? big.pool_bytes : 0, with_big ? big.npollers : 0);
       if (with_big) HIP_CHECK(hipStreamWaitEvent(st, W.ev_side, 0));
       HIP_CHECK(hipEventRecord(W.ev[nev + 1], st));
       timed.emplace_back(nev, nev + 1);
@@ -1842,7 +1850,9 @@ struct RawGraph {
     const bool wide = I.view.rs > 64;
     const bool old_general = T.old_general || with_cut || wide, force_general = T.force_general || with_cut || wide;
     // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
-    RoundCfg rc = config_for(I, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general);
+    // (dev: WANN_LEAN_POOL under WANN_TEST_HOOKS=1 gives the raw search the leaner per-wave pool too -- three workgroups per CU)
+    const int raw_pool = (T.hooks_live && T.lean_pool > 0) ? T.lean_pool : kSearchPoolBytes;
+    RoundCfg rc = config_for(I, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general, raw_pool);
     SearchArgs sa{};
     sa.ix = I.view;
     sa.queries = d_q.p;
@@ -1904,7 +1914,8 @@ struct RawGraph {
     if (verbose) {
       float ms = 0.f;
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-      fprintf(stderr, "[wann raw] beam %ld nq %ld kernel kind %d blocks %d: %.3f ms\n", (long)beam, (long)nq, rc.lc.big, rc.lc.blocks, ms);
+      fprintf(stderr, "[wann raw] beam %ld nq %ld kernel kind %d blocks %d (%d per CU by the runtime's occupancy): %.3f ms\n", (long)beam, (long)nq, rc.lc.big, rc.lc.blocks,
+              search_occupancy(sa, rc.lc), ms);
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
     }

@@ -847,13 +847,16 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     const int64_t deep_min = T.deep_min_tasks;
     int32_t deep = 0;
     // (worth a second launch only for a launch of a few milliseconds: tasks x first beam ~ hops)
-    if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && graph_n * b0 >= deep_min * 150 &&
-        T.deep && std::max<int64_t>(4 * b0, 256) <= cap1)
-      deep = T.deep_pollers;
     // Three workgroups per CU (a leaner LDS pool) where the kernel allows it and no companion workgroup has to share a CU with
     // the ordinary ones (the deep-chain pollers book whole CUs of their own)
     int base_pool = kSearchPoolBytes;
     if (big_n == 0 && !may_continue && T.lean && cap1 == kInKernelBeamCap && lean_pool_bytes(I) > 0) base_pool = lean_pool_bytes(I);
+    // How many: with two workgroups per CU (squared-L2 float kernel) four -- 16 cost the SIFT-1M 2^-3 batch 2.5 %; with three
+    // (twelve waves share a CU's memory path: a third level takes 2.2 ms there, 1.5 ms on a poller) every third-level chain
+    // should find one: 16 (deep-10M-like, eight such chains: 5.3 -> 4.5 ms per batch; 12 ... 32 measure alike).
+    if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && graph_n * b0 >= deep_min * 150 &&
+        T.deep && std::max<int64_t>(4 * b0, 256) <= cap1)
+      deep = T.deep_pollers > 0 ? T.deep_pollers : (base_pool != kSearchPoolBytes ? 16 : 4);
     launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue || deep > 0) ? big_cap : 0, deep, base_pool);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

@@ -35,7 +35,7 @@ struct Tuning {
   int heavy_ratio = 8;         // WANN_HEAVY_RATIO
   int spec_num = 8;            // WANN_SPEC_NUM
   int npollers = 0;            // WANN_POLLERS (0: 32 with the scan, else 16)
-  int deep_pollers = 4;        // WANN_DEEP_POLLERS
+  int deep_pollers = 0;        // WANN_DEEP_POLLERS (0: 4, or 16 where three workgroups share a CU)
   long long deep_min_tasks = 4096;  // WANN_DEEP_MIN_TASKS
   int scan_num = 16;           // WANN_SCAN_NUM
   int scan_min_top = 2560;     // WANN_SCAN_MIN_TOP
@@ -86,8 +86,8 @@ struct Tuning {
     if (t.spec_num < 1) t.spec_num = 1;
     t.npollers = num("WANN_POLLERS", 0);
     if (t.npollers < 0) t.npollers = 0;
-    t.deep_pollers = num("WANN_DEEP_POLLERS", 4);
-    if (t.deep_pollers < 1) t.deep_pollers = 1;
+    t.deep_pollers = num("WANN_DEEP_POLLERS", 0);
+    if (t.deep_pollers < 0) t.deep_pollers = 0;
     if (const char *v = getenv("WANN_DEEP_MIN_TASKS")) t.deep_min_tasks = atoll(v);
     t.scan_num = num("WANN_SCAN_NUM", 16);
     t.scan_min_top = num("WANN_SCAN_MIN_TOP", 2560);

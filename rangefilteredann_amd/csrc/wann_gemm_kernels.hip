@@ -631,6 +631,170 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
 #undef WANN_FETCHW
 }
 
+// Four slabs (rows of 385 .. 512 floats: RedCaps), fetch overlapped with the MFMAs (round 4).  The A operand alone is 256
+// registers there, so k_gemm_scores_wide<4> cannot keep a block in flight in registers and every half slab waited for its HBM
+// round trip in full, twice a slab.  Here the points travel HBM -> LDS directly (`global_load_lds_dwordx4`: no registers in
+// flight): a 32-KiB raw area R holds ONE half slab (64 points x 128 floats, a wave's 1 KiB per instruction, lane-contiguous),
+// and the unit of work is a half slab --
+//   wait for R | my 128 bytes of it -> bf16 pairs -> Ps rows of this half | barrier | request the NEXT half slab into R |
+//   the 48 MFMAs of this half (two point tiles x eight k-steps x three products)
+// -- one barrier per unit: the rows a unit stages were last read by the MFMAs two units back (every wave has passed a barrier
+// since), R is requested again only after every wave has read its part.  Row numbers and |p|^2 of the NEXT step are fetched
+// in units 4 .. 6 of a step and live in arrays that alternate by step parity (no barrier between a step's selection network
+// and the next step's staging).  Arithmetic, tile shapes, selection network and hand-over format are k_gemm_scores_wide's.
+__global__ __launch_bounds__(256, 1) void k_gemm_scores_wide4(GemmArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const IndexView &ix = A.ix;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int SLABS = 4, W = 128, S = W / 16, RB = 4 * W + 16, SR = 3;
+  unsigned char *Ps = smem;                                    // [128][RB]
+  float *base = reinterpret_cast<float *>(smem + 128 * RB);    // [2][128] per staged point: |p|^2 / 0, by step parity
+  int *rid = reinterpret_cast<int *>(base + 256);              // [2][128] point rows of a step, by step parity
+  u32x4 *const alds = reinterpret_cast<u32x4 *>(smem + 128 * RB + 4 * 128 * 4) + wv * (S * 64) + lane;  // low halves of the last slab's A operand
+  unsigned char *const R = smem + 128 * RB + 4 * 128 * 4 + 4 * S * 64 * 16;                             // raw half slab
+  constexpr int s4 = W >> 2, nit = s4 >> 1, nx = s4 >> 2;
+  const int half = lane >> 5, col = lane & 31;
+  const bool mips = ix.metric == 1;
+  const float scale = mips ? -1.f : -2.f;
+  const int ntiles = A.plan[P_NTILES];
+  const int stride = ix.stride;
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const GemmGroup grp = A.groups[A.tile_group[t]];
+    const int tl = t - grp.tile0, ch = tl / grp.nqt, q0 = (tl - ch * grp.nqt) << 7;
+    const int64_t w = grp.b - grp.a, wlast = w - 1;
+    const int64_t p_begin = (int64_t)ch * kGemmPointChunk;
+    const int64_t p_end = (p_begin + kGemmPointChunk < w) ? (p_begin + kGemmPointChunk) : w;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing of the previous tile is on its way into R any more)
+    __syncthreads();  // the previous tile is done with the staging area
+    if (tid < 128) rid[tid] = ix.fi_sorted[grp.a + min(p_begin + tid, wlast)];
+    u32x4 ah[S * SLABS], al[S * SR];
+    {
+      constexpr int DP = W + 4;
+      float *Qs = reinterpret_cast<float *>(Ps);
+      const int dlast = ix.d - 1;
+#pragma unroll
+      for (int sl = 0; sl < SLABS; sl++) {
+        if (sl) __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < nit; it++) {
+          const int idx = tid + it * 256;
+          const int r = idx / s4, c = W * sl + (idx - r * s4) * 4;
+          const bool live = q0 + r < grp.qcount;
+          const float *src = A.queries + (int64_t)A.gq[grp.qoff + (live ? q0 + r : grp.qcount - 1)] * ix.d;
+          f32x4 v;
+          v[0] = src[min(c + 0, dlast)]; v[1] = src[min(c + 1, dlast)]; v[2] = src[min(c + 2, dlast)]; v[3] = src[min(c + 3, dlast)];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = (live && c + e < ix.d) ? v[e] : 0.f;
+          *reinterpret_cast<f32x4 *>(Qs + r * DP + (c - W * sl)) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const float *qp = Qs + (32 * wv + col) * DP + 16 * s + 8 * half;
+          const f32x4 v0 = *reinterpret_cast<const f32x4 *>(qp), v1 = *reinterpret_cast<const f32x4 *>(qp + 4);
+          uint32_t h, l;
+          u32x4 lo4;
+          split2(v0[0], v0[1], h, l); ah[S * sl + s][0] = h; lo4[0] = l;
+          split2(v0[2], v0[3], h, l); ah[S * sl + s][1] = h; lo4[1] = l;
+          split2(v1[0], v1[1], h, l); ah[S * sl + s][2] = h; lo4[2] = l;
+          split2(v1[2], v1[3], h, l); ah[S * sl + s][3] = h; lo4[3] = l;
+          if (sl < SR) al[S * sl + s] = lo4;
+          else alds[s * 64] = lo4;
+        }
+      }
+    }
+    __syncthreads();
+    const int myrow = q0 + 32 * wv + col;
+    const bool live = myrow < grp.qcount;
+    const int64_t nsteps = (w + 127) >> 7;
+    f32x4 *erow = reinterpret_cast<f32x4 *>(A.scores + grp.soff) + ((int64_t)(live ? myrow : q0) * nsteps + (p_begin >> 7)) * 2 + half;
+    // half slab (SL, HF) of the step whose rows are ROWS -> R: thread (row tid >> 2 of the half, 16-byte column group tid & 3)
+    // brings eight pieces, 64 bytes apart; piece x of wave wv lands at R + (4 x + wv) KiB + 16 lane
+#define WANN_REQUEST(ROWS, SL, HF)                                                                                        \
+  {                                                                                                                       \
+    const float *src_ = ix.points + (int64_t)(ROWS)[64 * (HF) + (tid >> 2)] * stride;                                     \
+    _Pragma("unroll") for (int x = 0; x < nx; x++)                                                                        \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + min(W * (SL) + 4 * (tid & 3) + 16 * x, stride - 4)), \
+                                       (__attribute__((address_space(3))) void *)(R + (4 * x + wv) * 1024), 16, 0, 0);     \
+  }
+    float pre_n = 0.f;
+    int pre_rid = 0;
+    if (tid < 128) pre_n = A.pnorm2[rid[tid]];
+    WANN_REQUEST(rid, 0, 0)
+    f32x16 acc[4];
+    int par = 0;
+    for (int64_t c0 = p_begin; c0 < p_end; c0 += 128, par ^= 1) {
+      int *const rid_cur = rid + 128 * par, *const rid_nxt = rid + 128 * (par ^ 1);
+      float *const base_cur = base + 128 * par;
+#pragma unroll
+      for (int sl = 0; sl < SLABS; sl++) {
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the unit have landed (and the row numbers / norms asked for earlier)
+          {
+            unsigned char *dst = Ps + (64 * hf + (tid >> 2)) * RB + 8 * (tid & 3);
+#pragma unroll
+            for (int x = 0; x < nx; x++) {
+              f32x4 v = *reinterpret_cast<const f32x4 *>(R + (4 * x + wv) * 1024 + 16 * lane);
+              if (W * sl + 4 * (tid & 3) + 16 * x >= stride) v = f32x4{0.f, 0.f, 0.f, 0.f};  // beyond the row: zero
+              uint32_t h0, l0, h1, l1;
+              split2(v[0], v[1], h0, l0);
+              split2(v[2], v[3], h1, l1);
+              *reinterpret_cast<uint2 *>(dst + 32 * x) = make_uint2(h0, h1);
+              *reinterpret_cast<uint2 *>(dst + 2 * W + 32 * x) = make_uint2(l0, l1);
+            }
+          }
+          if (tid < 128) {
+            if (sl == 0 && hf == 0) base_cur[tid] = (c0 + tid < p_end) ? (mips ? 0.f : pre_n) : kHuge;  // positions beyond the window never win
+            if (sl == 2 && hf == 0) pre_rid = ix.fi_sorted[grp.a + min(c0 + 128 + tid, wlast)];
+            if (sl == 2 && hf == 1) rid_nxt[tid] = pre_rid;
+            if (sl == 3 && hf == 0) pre_n = A.pnorm2[rid_nxt[tid]];
+          }
+          __syncthreads();  // the unit is staged; R is free
+          if (hf == 0) WANN_REQUEST(rid_cur, sl, 1)
+          else if (sl + 1 < SLABS) WANN_REQUEST(rid_cur, sl + 1, 0)
+          else if (c0 + 128 < p_end) WANN_REQUEST(rid_nxt, 0, 0)
+          if (sl == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[2 * hf][r] = acc[2 * hf + 1][r] = 0.f;
+          }
+          const unsigned char *pb = Ps + col * RB + 16 * half;
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah[S * sl + s]);
+            const bf16x8 a_lo = __builtin_bit_cast(bf16x8, sl < SR ? al[S * sl + s] : alds[s * 64]);
+#pragma unroll
+            for (int j = 2 * hf; j < 2 * hf + 2; j++) {
+              const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB + 32 * s);
+              const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(pb + j * 32 * RB + 2 * W + 32 * s);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, a_hi, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, a_lo, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, a_hi, acc[j], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // the four smallest of this lane's 64 scores, sorted; low six mantissa bits = 16 j + reg (which position)
+      float m1 = kHuge, m2 = kHuge, m3 = kHuge, m4 = kHuge;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(base_cur + 32 * j + 8 * g + 4 * half);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float sc = fmaf(scale, acc[j][4 * g + r], b4[r]);
+            const float x = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(16 * j + 4 * g + r));
+            insert4(m1, m2, m3, m4, x);
+          }
+        }
+      if (live) erow[(c0 - p_begin) >> 6] = f32x4{m1, m2, m3, m4};
+    }
+#undef WANN_REQUEST
+  }
+}
+
 // One wave per grouped query.  Its window's blocks each handed over their four smallest scores (sorted, position in
 // the low mantissa bits).  The first three of every block are candidates, the fourth bounds everything the block kept
 // to itself.  The kSelect best candidates live sorted in lanes 0 .. kSelect-1 (score bits in one register, window
@@ -857,8 +1021,10 @@ int launch_gemm_scores(const GemmArgs &a, int num_cus, void *stream) {
       return 1;
     }
     const int slabs = (a.ix.stride + 127) / 128;
-    const size_t ldsw = (size_t)128 * (4 * 128 + 16) + 3 * 128 * 4 + (slabs == 4 ? (size_t)4 * 8 * 64 * 16 : 0);
-    void (*kw)(GemmArgs) = slabs == 2 ? k_gemm_scores_wide<2> : slabs == 3 ? k_gemm_scores_wide<3> : k_gemm_scores_wide<4>;
+    // (four slabs: + the low halves of the last slab's A operand; the overlapped kernel: + its parity arrays and the raw half slab)
+    const bool wide4 = slabs == 4 && WANN_AB != 8;
+    const size_t ldsw = (size_t)128 * (4 * 128 + 16) + (wide4 ? 4 : 3) * 128 * 4 + (slabs == 4 ? (size_t)4 * 8 * 64 * 16 : 0) + (wide4 ? (size_t)32 * 1024 : 0);
+    void (*kw)(GemmArgs) = slabs == 2 ? k_gemm_scores_wide<2> : slabs == 3 ? k_gemm_scores_wide<3> : wide4 ? k_gemm_scores_wide4 : k_gemm_scores_wide<4>;
     if (gcheck(hipFuncSetAttribute((const void *)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw))) return 1;
     hipLaunchKernelGGL(kw, dim3(num_cus > 0 ? num_cus : 256), dim3(256), ldsw, (hipStream_t)stream, a);
     return gcheck(hipGetLastError());

@@ -1,5 +1,7 @@
 #!/bin/bash
 # mid window fractions: at most half the pollers run look-aheads asked for on evidence; chains beyond their levels go to idle pollers from 8 x the first beam
+# (WANN_LA_SPEC_CAP / WANN_COMPANION_HANDOFF belong to an experimental build that was reverted -- DESIGN.md section 7, open item 1; the
+#  shipped library ignores them.  Kept as the record of profiles/r04_mid_fraction_schedule_sweeps.txt.)
 export TMPDIR=/tmp
 O=gpurun_out/r04handoff
 mkdir -p $O

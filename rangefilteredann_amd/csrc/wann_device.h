@@ -276,6 +276,8 @@ struct LaunchCfg {
 };
 int launch_route(const RouteArgs &a, void *stream);
 int launch_order_heavy(const OrderArgs &a, void *stream);
+// a one-thread kernel that ends when *resident >= need (or after ~0.25 ms): orders the ordinary launch behind the companion's start
+int launch_gate(const int32_t *resident, int need, void *stream);
 int launch_search(const SearchArgs &a, const LaunchCfg &cfg, void *stream);
 // workgroups of that launch the runtime expects to be resident per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor); -1 on error
 int search_occupancy(const SearchArgs &a, const LaunchCfg &cfg);

@@ -805,6 +805,13 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         HIP_CHECK(hipStreamWaitEvent(side, W.ev[nev], 0));
         if (launch_search(big, big_lc, side)) throw HipError(std::string("k_search (big): ") + launch_last_error());
         HIP_CHECK(hipEventRecord(W.ev_side, side));
+        // The deep-chain pollers book whole CUs, and nothing makes room for them once the ordinary launch has booked every
+        // CU for the length of the batch (its workgroups are persistent; the ones that yield free half a CU each).  Which of
+        // the two hardware queues reaches the CUs first differed from call to call: on the SIFT-1M 2^-3 batch every second
+        // call handed 0 - 3 of its 4 third-level chains over instead of 4 and took 3.19 instead of 2.76 ms.  A one-thread
+        // kernel holds this stream until the pollers have started.
+        if (deep_pollers > 0 && T.gate)
+          if (launch_gate(W.ints.p + I_BIG_RESIDENT, big.npollers, st)) throw HipError(std::string("k_gate: ") + launch_last_error());
       }
       if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
       if (T.verbose)

@@ -24,6 +24,7 @@ struct Tuning {
   bool yield = true;           // !WANN_NO_YIELD
   bool helper = true;          // !WANN_NO_HELPER: scoring helper waves of the one-wave kernel
   bool deep = true;            // !WANN_NO_DEEP
+  bool gate = true;            // !WANN_NO_GATE: the ordinary launch waits for the deep-chain pollers to start
   bool lookahead = true;       // !WANN_NO_LOOKAHEAD
   bool scan = true;            // WANN_SCAN != 0
   bool evidence_first = true;  // !WANN_NO_EVIDENCE_FIRST
@@ -72,6 +73,7 @@ struct Tuning {
     t.yield = !set("WANN_NO_YIELD");
     t.helper = !set("WANN_NO_HELPER");
     t.deep = !set("WANN_NO_DEEP");
+    t.gate = !set("WANN_NO_GATE");
     t.lookahead = !set("WANN_NO_LOOKAHEAD");
     t.scan = !(set("WANN_SCAN") && num("WANN_SCAN", 1) == 0);
     t.evidence_first = !set("WANN_NO_EVIDENCE_FIRST");

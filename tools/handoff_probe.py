@@ -14,8 +14,8 @@ cache = f"/tmp/wann_fullsize_cache/{name}_n{cfg['n']}/"
 t0 = time.time()
 idx = fc.make_index(wa, name, X, labels, cache)
 print(f"index ready in {time.time() - t0:.0f}s", flush=True)
-beam = 80
-W = fc.fraction_windows(labels, cfg["nq"], -3, 1997).astype(np.float32)
+beam, frac = (40, -6) if name == "glove" else (80, -3)
+W = fc.fraction_windows(labels, cfg["nq"], frac, 1997).astype(np.float32)
 a = (Q, W, cfg["nq"]) + ((cfg["method"],) if cfg["method"] is not None else ())
 hist = []
 for i in range(calls):

@@ -343,7 +343,11 @@ struct RoundCfg {
 // what a beam that does not fit the LDS next to the helper waves' mailbox gets.  The production one-wave kernel
 // (k_search<., 1>) always keeps its seen-filter in global memory.
 // base_pool: the four-wave kernel's per-wave pool (kSearchPoolBytes, or lean_pool_bytes() for three workgroups per CU).
-constexpr int kLdsBudget = 156 * 1024;  // of the 160 KiB per CU: what co-resident workgroups can be counted on to share (lean_pool_bytes)
+// A workgroup's LDS is handed out in granules: 1 280 bytes fits what round 4 measured (three workgroups of 53 KiB = 43 granules each
+// are not co-resident in a CU's 128 granules, three of 52.5 KiB = 42 are; two of 77.5 KiB = 62 are) -- whatever
+// hipOccupancyMaxActiveBlocksPerMultiprocessor says.
+constexpr int kLdsGranule = 1280, kLdsPerCu = 160 * 1024;
+inline int lds_blocks_per_cu(int per_block) { return kLdsPerCu / (((per_block + kLdsGranule - 1) / kLdsGranule) * kLdsGranule); }
 
 RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false,
                     bool legacy = false, int base_pool = kSearchPoolBytes) {
@@ -371,7 +375,7 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   // (four-wave kernel: the squared-L2 float kernel needs 232 registers: two waves per SIMD; the inner-product and byte-row
   // kernels are built for three)
   const int waves_per_cu = (I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32) ? 12 : 8;
-  int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, kLdsBudget / per_block);  // (see lean_pool_bytes: the last 4 KiB do not count)
+  int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, lds_blocks_per_cu(per_block));
   blocks_per_cu = std::max(1, blocks_per_cu);
   if (I.tune.blocks_per_cu > 0) blocks_per_cu = std::max(1, std::min(blocks_per_cu, I.tune.blocks_per_cu));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;

@@ -310,9 +310,11 @@ void upload_index(wann_index &I) {
 // (entries tagged with the slot's search epoch), the epochs, and the per-slot exact seen bitmaps.  A table whose
 // slot layout changes (or that was reallocated) is zeroed together with its epochs.
 void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBuf<uint32_t> &seen, int64_t &layout, int slots,
-                           int table_bits, int64_t seen_words, hipStream_t st) {
+                           int table_bits, int64_t seen_words, hipStream_t st, bool any_slots = false) {
   const size_t need = (size_t)slots << table_bits;
-  const int64_t want = ((int64_t)slots << 8) | table_bits;
+  // any_slots: a slot's region depends on the table size only (slot << table_bits), so launches with different slot counts
+  // share one zeroed table
+  const int64_t want = any_slots ? (int64_t)table_bits : (((int64_t)slots << 8) | table_bits);
   const bool fresh = need > table.cap || (size_t)slots > epoch.cap;
   table.ensure(need);
   epoch.ensure((size_t)slots);
@@ -792,9 +794,16 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
           a.g_epoch = W.g_epoch_f.p;
           a.g_seen = W.g_seen_f.p;
           a.g_seen_words = seen_words;
-        } else {  // four-wave kernel (first-generation general core): a plain per-slot table, cleared per search
-          W.g_table.ensure((size_t)rc.slots << rc.table_bits);
+        } else if (rc.lc.big == 0) {  // four-wave kernel (third-generation general core): tagged filter entries, no seen bitmaps
+          // (the slot count of this launch follows the batch size: the layout key is the table size alone, and the buffers
+          // only ever grow -- a fresh allocation is zeroed whole)
+          ensure_filter_scratch(W.g_table, W.g_epoch, W.g_seen, W.g_table_layout, rc.slots, rc.table_bits, 0, st, /*any_slots=*/true);
           a.g_table = W.g_table.p;
+          a.g_epoch = W.g_epoch.p;
+        } else {  // legacy one-wave kernel (first-generation general cores): a plain per-slot table, cleared per search
+          W.g_table_f.ensure((size_t)rc.slots << rc.table_bits);
+          a.g_table = W.g_table_f.p;
+          W.g_table_f_layout = -1;  // (plain ids are in it now)
         }
         a.g_table_bits = rc.table_bits;
       }

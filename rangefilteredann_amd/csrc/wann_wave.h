@@ -502,7 +502,10 @@ __device__ __forceinline__ float wave_distances(const IndexView &ix, const int32
 // prev_key / prev_mask (rows of more than 64 neighbours are worked in two halves, wave_beam_search): the passing candidates of the
 // row's FIRST half, in their lanes -- a copy of one of them among this call's candidates counts as a further copy of the same
 // std::set_union operand (the reference unions the whole row's candidates at once).
-template <typename BeamPtr, bool DEDUP = true, bool PRESORTED = false>
+// COLLAPSE (wave_beam_search_mid: the candidates of SEVERAL hops, none of which holds a key twice, united in one go): hop after hop
+// the reference's union would keep max(copies in the beam, copies in the hop) of a key -- so a key the beam holds is dropped and
+// equal candidates (the same node scored in two hops) count once.
+template <typename BeamPtr, bool DEDUP = true, bool PRESORTED = false, bool COLLAPSE = false>
 __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass, u64 key,
                                           u64 *cand_key, int *first_pos, u64 prev_key = 0ull, u64 prev_mask = 0ull) {
   const int lane = lane_id();
@@ -572,7 +575,7 @@ __device__ __forceinline__ int wave_merge(BeamPtr beam, int m, int B, bool pass,
     int j = prior, bx = 0;
     for (int l = lane - 1; l >= 0 && cand_key[l] == ck; l--) j++;
     while (pos + bx < m && ((beam[pos + bx] | 1ull) == (ck | 1ull))) bx++;
-    dup = j < bx;
+    dup = COLLAPSE ? (j > 0 || bx > 0) : (j < bx);
   }
   WAVE_SYNC();
   const u64 nd = ballot64(mine && !dup);
@@ -1709,6 +1712,500 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     atomicAdd(&ctr->own_scorings, (unsigned long long)st_own);
     atomicAdd(&ctr->prefetched_hops, (unsigned long long)st_nx);
   }
+  m_out = M;
+  nvis_out = nvis;
+  ncmp_out = 1 + ncmp_v;
+}
+
+// --------------------------------------------------------------------------------------------
+// Third-generation general core: beams that do not fit the register-resident variant, in the FOUR-wave kernel
+// (129 .. its cap; round 5).  The search of wave_beam_search<.., false, true, false> -- sorted beam in the LDS, lossy
+// seen-filter in global memory, same union -- with its three dependent memory round trips per hop (adjacency row ->
+// filter probes -> vectors) taken out of the chain of hops WITHOUT helper waves: the wave itself keeps them in flight
+// across hops.
+//
+//  * Which node the next hops visit is nearly always known: the first unvisited beam entries behind the current one
+//    (measured on the oracle: 89 % of the hops at beam 160, 94 % at 320, 97 % at 640, 98.5 % at 1 280).  The rows of the
+//    next TWO expected nodes are requested as soon as they are known (slots s1 / s2, one register each), and the filter
+//    probes of the next expected node right after the current hop's filter stores (same wave, program order: they see
+//    them).  Row, filter slots and slot-sharing test are pure functions of the node; the probes are valid exactly while
+//    no other hop's stores have followed them.
+//  * EARLY COMMIT.  Once a hop's distances are known, so is whether the expectation holds: it does unless a passing
+//    candidate sorts at or before the expected node.  If it holds, the NEXT hop's filter step (sequential semantics kept:
+//    it runs after this hop's) and its vector requests are issued BEFORE this hop's union, which then runs under the
+//    vectors' round trip.  The union's result is needed only for the next hop's cutoff, applied when its distances return.
+//    A hop of the steady state is one memory round trip (the vectors) + distance arithmetic, instead of three round trips
+//    + union.
+//  * Vectors are requested at one point of the hop and consumed at another (RowRegs: half a row per lane, one row per
+//    lane pair and pass, ids and results through the cross-lane network as in wave_distances_own), for the row shapes
+//    with a compile-time routine; other shapes are fetched where they are scored.
+//  * Filter entries are tagged with the slot's search epoch (as in wave_beam_search_big): no table clear per search.
+//
+// Everything with sequential semantics -- lossy filter, cutoff, union, visit order -- happens in the reference's order;
+// a wrong expectation costs the round trips it would have cost anyway.  Results, hops and dist_cmps are those of
+// wave_beam_search (the parity tests run every core against the oracle).
+// --------------------------------------------------------------------------------------------
+// (NR = the most blocks a lane holds: what the kernel's register budget affords -- 16 in the squared-L2 float kernel (two waves
+// per SIMD), fewer or none in the kernels built for three)
+#if WANN_DT != 0
+constexpr int kRowRegs = 8;  // byte rows of up to 256 elements
+#else
+constexpr int kRowRegsL2 = 16, kRowRegsMips = 0;
+#endif
+template <int NR>
+struct RowRegs {
+  float4 v[NR > 0 ? NR : 1];
+};
+template <int METRIC>
+struct RowRegsFor {
+#if WANN_DT != 0
+  static constexpr int NR = kRowRegs;
+#else
+  static constexpr int NR = METRIC == 1 ? kRowRegsMips : kRowRegsL2;
+#endif
+  typedef RowRegs<NR> type;
+};
+
+// how many 16-byte blocks of a row a lane holds in RowRegs (wave-uniform); 0: this row shape is fetched where it is scored.
+// (ONE loader and one scoring routine per metric, blocks predicated by the count: a switch over compile-time routines made
+// hipcc merge the cases' loads into one block with an address register pair per load -- 270 registers.)
+template <int METRIC>
+__device__ __forceinline__ int row_regs_blocks(const IndexView &ix) {
+#if WANN_DT != 0
+  const int chunks = ix.stride >> 3;  // 16-byte chunks per lane
+  return chunks <= RowRegsFor<METRIC>::NR ? chunks : 0;
+#else
+  if (METRIC == 1) {
+    const int np = (((ix.d + 3) >> 2) + 1) >> 1;
+    return np <= RowRegsFor<METRIC>::NR ? np : 0;
+  }
+  const int D8 = (ix.d + 7) >> 3;  // (an odd block count starts with the LAST block, NSGDist.h:40-47: only 13 -- d = 100 -- is served)
+  return (D8 <= RowRegsFor<METRIC>::NR && (!(D8 & 1) || D8 == 13)) ? D8 : 0;
+#endif
+}
+
+// lane h of a pair holds the 16-byte blocks 2 j + h of its row, j < nblk -- the same addresses for float32 rows under either
+// metric and for byte rows
+template <int NR>
+__device__ __forceinline__ void row_regs_load(RowRegs<NR> &rr, const float *__restrict__ prow, int h, int nblk) {
+#pragma unroll
+  for (int j = 0; j < NR; j++)
+    if (j < nblk) rr.v[j] = *reinterpret_cast<const float4 *>(prow + 8 * j + 4 * h);
+}
+
+template <int METRIC, int NR>
+__device__ __forceinline__ float row_regs_score(const RowRegs<NR> &rr, const float *qv, const IndexView &ix, int h, int nblk) {
+  if (NR == 0) return 0.f;
+#if WANN_DT != 0
+  int ab = 0, aa = 0, qq = 0;  // byte_pair's arithmetic (exact integer sums: any order)
+#pragma unroll
+  for (int j = 0; j < NR; j++)
+    if (j < nblk) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(qv + 8 * j + 4 * h);
+      const uint4 p = __builtin_bit_cast(uint4, rr.v[j]);
+      ab = dot4_acc(p.x, q.x, ab);
+      ab = dot4_acc(p.y, q.y, ab);
+      ab = dot4_acc(p.z, q.z, ab);
+      ab = dot4_acc(p.w, q.w, ab);
+      if (METRIC == 0) {
+        aa = dot4_acc(p.x, p.x, aa);
+        aa = dot4_acc(p.y, p.y, aa);
+        aa = dot4_acc(p.z, p.z, aa);
+        aa = dot4_acc(p.w, p.w, aa);
+        qq = dot4_acc(q.x, q.x, qq);
+        qq = dot4_acc(q.y, q.y, qq);
+        qq = dot4_acc(q.z, q.z, qq);
+        qq = dot4_acc(q.w, q.w, qq);
+      }
+    }
+  const int mine = METRIC == 0 ? (aa + qq - 2 * ab) : ab;
+  const int both = mine + __shfl_xor(mine, 1);
+  return METRIC == 0 ? (float)both : -(float)both;
+#else
+  if (METRIC == 1) {  // mips_pair_ct's arithmetic: one running scalar, products rounded then added in index order, fused tail
+    const int tail_from = (ix.d & ~7) >> 3;
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < NR; t++)
+      if (t < nblk) {
+        const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * t + 4 * h);
+        r = mips_step(r, rr.v[t], q, t >= tail_from);
+      }
+    return -r;
+  }
+  // l2_pair_ct's arithmetic: blocks in the reference's order (an odd count: last block first)
+  f32x2 alo = {0.f, 0.f}, ahi = {0.f, 0.f};
+  int nfull = nblk;
+  if (NR > 12 && nblk == 13) {
+    const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * 12 + 4 * h);
+    sq_acc(alo, ahi, rr.v[NR > 12 ? 12 : 0], q);
+    nfull = 12;
+  }
+#pragma unroll
+  for (int i = 0; i < NR; i++)
+    if (i < nfull) {
+      const float4 q = *reinterpret_cast<const float4 *>(qv + 8 * i + 4 * h);
+      sq_acc(alo, ahi, rr.v[i], q);
+    }
+  const float s = ((alo.x + alo.y) + ahi.x) + ahi.y;
+  const float other = __shfl_xor(s, 1);
+  return (((other + alo.x) + alo.y) + ahi.x) + ahi.y;
+#endif
+}
+
+// Request the rows of a hop's kept neighbours (lanes flagged `take`, entry `a`): the r-th flagged lane pushes its id to lane
+// pair r (first pass: r < 32), the pair's lanes request half a row each.  r / nt: rank of this lane among the flagged, their number.
+template <int METRIC>
+__device__ __forceinline__ void mid_request_rows(const IndexView &ix, int a, bool take, int64_t row_off, int mode,
+                                                 typename RowRegsFor<METRIC>::type &rr, int &r, int &nt) {
+  const int lane = lane_id();
+  const u64 tm = ballot64(take);
+  nt = popc64(tm);
+  r = popc64(tm & lanemask_lt());
+  if (RowRegsFor<METRIC>::NR == 0 || mode == 0 || nt == 0) return;
+  const bool now = take && r < 32;
+  const int got = __builtin_amdgcn_ds_permute(now ? (r << 3) : 4, a);
+  const int ev = pair_even_value(got);
+  const int id = ((lane >> 1) < nt) ? ev : 0;  // idle pairs fetch node 0: no branches
+  row_regs_load(rr, ix.points + (row_off + id) * (int64_t)ix.stride, lane & 1, mode);
+}
+
+// ... and their distances: every flagged lane receives the distance of its entry
+template <int METRIC>
+__device__ __forceinline__ float mid_take_distances(const IndexView &ix, int a, bool take, int64_t row_off, const float *qv, int mode,
+                                                    const typename RowRegsFor<METRIC>::type &rr, int r, int nt) {
+  if (nt == 0) return 0.f;
+  if (RowRegsFor<METRIC>::NR == 0 || mode == 0) return wave_distances_own<METRIC, true>(ix, a, take, qv, row_off);
+  const int lane = lane_id(), h = lane & 1;
+  float mine = 0.f;
+  {
+    const float dd = row_regs_score<METRIC>(rr, qv, ix, h, mode);
+    const float back = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((r << 1) | 1) << 2, __builtin_bit_cast(int, dd)));
+    if (take && r < 32) mine = back;
+  }
+  if (WANN_UNLIKELY(nt > 32)) {  // (more than 32 new neighbours: a search's first hops)
+    const bool now = take && r >= 32;
+    const int got = __builtin_amdgcn_ds_permute(now ? ((r - 32) << 3) : 4, a);
+    const int ev = pair_even_value(got);
+    const int id = (32 + (lane >> 1) < nt) ? ev : 0;
+    typename RowRegsFor<METRIC>::type r2;  // (registers of its own: `rr` has ONE definition per hop, or the compiler copies it around)
+    row_regs_load(r2, ix.points + (row_off + id) * (int64_t)ix.stride, h, mode);
+    const float dd = row_regs_score<METRIC>(r2, qv, ix, h, mode);
+    const float back = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((((r - 32) << 1) | 1) << 2, __builtin_bit_cast(int, dd)));
+    if (now) mine = back;
+  }
+  return mine;
+}
+
+template <int METRIC>
+__device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const PartDesc &part, const WaveLds &L, int32_t *gtable,
+                                                     uint32_t tag, int B, int bits, int64_t qid, int64_t limit, int degree_limit,
+                                                     int32_t *mini, uint32_t mini_mask, int &m_out, long long &nvis_out,
+                                                     long long &ncmp_out, unsigned long long *prof = nullptr) {
+  prof = WANN_PROF_PTR(prof);
+  // (every wave-uniform argument into scalar registers: see wave_beam_search_big)
+  tag = (uint32_t)uni((int)tag);
+  B = uni(B);
+  bits = uni(bits);
+  qid = uni64(qid);
+  degree_limit = uni(degree_limit);
+  mini_mask = (uint32_t)uni((int)mini_mask);
+  const int lane = lane_id();
+  const uint32_t tmask = (1u << bits) - 1u;
+  const int64_t row_off = uni(part.start);
+  const int64_t row_base = uni64(part.row_base);
+  const int rs = uni(ix.rs);
+  u64 *const mb = L.lbeam;
+  const int mode = (WANN_AB == 2 || RowRegsFor<METRIC>::NR == 0) ? 0 : uni(row_regs_blocks<METRIC>(ix));  // (blocks of a row a lane holds; 0: rows fetched where they are scored)
+  const int lim = uni(limit > 0x7fffffff ? 0x7fffffff : (int)limit);
+
+  // frontier = {start node 0} (beamSearch.h:80-82)
+  if (lane == 0) L.cand_id[0] = 0;
+  WAVE_SYNC();
+  float d0 = wave_distances<METRIC>(ix, L.cand_id, L.cand_dist, L.qv, 1, row_off);
+  d0 = __shfl(d0, 0);
+  const u64 key0 = (u64)fkey(d0) << 32;
+  if (lane == 0) mb[0] = key0;
+  WAVE_SYNC();
+  int M = 1, nvis = 0, ncmp_v = 0;  // entries of the LDS beam; hops; dist_cmps (counted per lane, summed at the end)
+  // PENDING candidates: pend[0 .. D), pmin = the smallest of their keys (~0: none).  The beam is the LDS beam united with
+  // them, truncated to B; the union is deferred (see above).  (pend: the 512 bytes of cand_id + cand_dist, which this core
+  // uses for the start node only; cand_key is the union's scratch and may double as the slot-sharing test's)
+  u64 *const pend = reinterpret_cast<u64 *>(L.cand_id);
+  int D = 0;
+  u64 pmin = ~0ull;
+  float cutoff = 2147483648.0f;  // (float)INT_MAX while the LDS beam is not full, else its last distance: never below the true cutoff
+  // window: wv = mb[wbase + lane]; bit i of wum: entry wbase + i exists and is unvisited
+  int wbase = 0;
+  u64 wv = lane == 0 ? key0 : 1ull, wum = 1ull;
+  // the hop in flight: node at position pos_c, its row `a`, the neighbours the reference scores (`kept`), their vectors requested;
+  // hop_exact: two of them share a filter slot (the row may list a node twice: its candidates are united at once, multiset rule)
+  int pos_c = -1, a = -1, sc_r = 0, sc_nt = 0, scan_from = 0;
+  bool kept = false, have = false, hop_exact = false;
+  typename RowRegsFor<METRIC>::type rr;
+  // the next two expected nodes: s1 (key s1k at position s1p; row s1a; filter slots s1loc; probes s1old, valid while s1probe;
+  // s1clash: two of its neighbours share a filter slot) and s2 (row s2a)
+  int s1n = -1, s1p = 0, s2n = -1, s1a = -1, s2a = -1, s1old = 0;
+  u64 s1k = 0;
+  uint32_t s1loc = 0;
+  bool s1probe = false, s1clash = false;
+
+  auto load_row = [&](int node) -> int {  // graph.h:198; -1 = unused slot
+    int v = -1;
+    if (lane < rs) v = ix.graph[(row_base + node) * (int64_t)rs + lane];
+    return v;
+  };
+  auto is_valid = [&](int arow) -> bool { return (arow >= 0) && (lane < degree_limit) && ((int64_t)arow != qid); };
+  // filter slots of a row + the exact test "two valid lanes of the row share a filter slot" (see wave_beam_search_big)
+  auto prepare = [&](int arow, uint32_t &loc, bool &clash) {
+    loc = (uint32_t)hash64_2((u64)(uint32_t)arow) & tmask;
+    const bool valid = is_valid(arow);
+    const uint32_t mh = loc & mini_mask;
+    if (valid) mini[mh] = lane;
+    WAVE_SYNC();
+    const int mw = valid ? mini[mh] : lane;
+    WAVE_SYNC();
+    const uint32_t loc_w = (uint32_t)__shfl((int)loc, mw);
+    const bool lost = valid && (mw != lane);
+    bool c = ballot64(lost && loc_w == loc) != 0;
+    for (u64 um = ballot64(lost && loc_w != loc); um && !c; um &= um - 1) {
+      const int u = ctz64(um);
+      const uint32_t lu = (uint32_t)rdlane((int)loc, u);
+      c = ballot64(valid && loc == lu && lane != u) != 0;
+    }
+    clash = uni((int)c) != 0;
+  };
+  // lossy seen-filter with the reference's sequential semantics (beamSearch.h:68-73,126-131): what the reference scores
+  auto filter = [&](int arow, uint32_t loc, int old, bool clash) -> bool {
+    const bool valid = is_valid(arow);
+    const int tagged = (int)(tag | (uint32_t)arow);
+    bool seen;
+    if (WANN_LIKELY(!clash)) {
+      seen = valid && (old == tagged);
+      if (valid) gtable[loc] = tagged;
+    } else {  // exact emulation: the nearest preceding lane of the same slot, else the table; the last lane of a slot class stores
+      u64 eq = ballot64(valid);
+      for (int b = 0; b < bits; b++) {
+        const bool bit = (loc >> b) & 1u;
+        const u64 bm = ballot64(valid && bit);
+        eq &= bit ? bm : ~bm;
+      }
+      const u64 lower = valid ? (eq & lanemask_lt()) : 0ull;
+      const u64 higher = (lane == 63) ? 0ull : (eq >> (lane + 1));
+      const int prev_lane = lower ? (63 - __builtin_clzll(lower)) : lane;
+      const int prev_val = __shfl(arow, prev_lane);
+      seen = valid && (lower ? (prev_val == arow) : (old == tagged));
+      if (valid && higher == 0) gtable[loc] = tagged;
+    }
+    const bool k = valid && !seen;
+    ncmp_v += k ? 1 : 0;
+    return k;
+  };
+  auto set_cutoff = [&]() {
+    cutoff = 2147483648.0f;
+    if (M >= B) cutoff = funkey((uint32_t)(mb[M - 1] >> 32));
+  };
+  // the pending candidates into the LDS beam (std::set_union + truncate, beamSearch.h:148-157, for all their hops at once)
+  auto unite_pending = [&]() {
+    if (D == 0) return;
+    const u64 k = lane < D ? pend[lane] : 0ull;
+    WAVE_SYNC();
+    int p0;
+    M = wave_merge<u64 *, true, false, true>(mb, M, B, lane < D, k, L.cand_key, &p0);
+    scan_from = p0 < scan_from ? p0 : scan_from;
+    D = 0;
+    pmin = ~0ull;
+    set_cutoff();
+  };
+  auto load_window = [&](int from) {
+    wbase = from;
+    const int x = from + lane;
+    wv = x < M ? mb[x] : 1ull;
+    wum = ballot64(!(wv & 1ull));
+  };
+  // The first two unvisited entries of the window become s1 / s2.  Rows on hand are kept (by node: a row is a pure function of
+  // it), the others requested; s1's probes go out if its row is on hand (they follow the current hop's filter stores; a row
+  // requested just now returns behind whatever is in flight: its probes go out when that is consumed).  Nothing is in flight
+  // when this runs: registers move freely.
+  auto expect = [&]() {
+    if (WANN_UNLIKELY(popc64(wum) < 2 && wbase + 64 < M)) load_window(wum ? wbase + ctz64(wum) : wbase + 64);
+    int g1 = -1, g2 = -1, p1 = 0;
+    u64 k1 = 0;
+    if (wum) {
+      const int i = ctz64(wum);
+      k1 = rdlane64(wv, i);
+      g1 = (int)((uint32_t)k1 >> 1);
+      p1 = wbase + i;
+      const u64 rest = wum & (wum - 1);
+      if (rest) g2 = (int)((uint32_t)rdlane((int)(uint32_t)wv, ctz64(rest)) >> 1);
+    }
+    // (Order matters to the compiler's wait insertion: a use of a register that MAY be the target of a request just issued -- on
+    // any path -- waits for every request before it.  So: first everything that works on rows on hand, then the new requests.)
+    const int o1n = s1n, o2n = s2n;
+    const int o1a = s1a, o2a = s2a;
+    const bool hand1 = g1 >= 0 && (g1 == o1n || g1 == o2n);
+    if (g1 != o1n) {
+      s1probe = false;
+      if (g1 == o2n) s1a = o2a;
+    }
+    const bool hand2 = g2 >= 0 && (g2 == o2n || g2 == o1n);
+    if (g2 == o1n && g2 != o2n) s2a = o1a;
+    s1n = g1;
+    s1k = k1;
+    s1p = p1;
+    s2n = g2;
+    if (hand1 && !s1probe) {
+      prepare(s1a, s1loc, s1clash);
+      s1old = gtable[s1loc];
+      s1probe = true;
+    }
+    if (g1 >= 0 && !hand1) s1a = load_row(g1);
+    if (g2 >= 0 && !hand2) s2a = load_row(g2);
+  };
+
+  unsigned long long tp = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WANN_PHASE(i)                                       \
+  do {                                                      \
+    if (prof) {                                             \
+      unsigned long long tn = __builtin_readcyclecounter(); \
+      acc[i] += tn - tp;                                    \
+      tp = tn;                                              \
+    }                                                       \
+  } while (0)
+  if (prof) tp = __builtin_readcyclecounter();
+  for (;;) {
+    // (the loop-carried scalars, declared uniform once per hop: see wave_beam_search_big)
+    M = uni(M);
+    D = uni(D);
+    nvis = uni(nvis);
+    pos_c = uni(pos_c);
+    scan_from = uni(scan_from);
+    wbase = uni(wbase);
+    s1n = uni(s1n);
+    s1p = uni(s1p);
+    s2n = uni(s2n);
+    wum = (u64)uni64((long long)wum);
+    pmin = (u64)uni64((long long)pmin);
+    s1k = (u64)uni64((long long)s1k);
+    s1probe = uni((int)s1probe) != 0;
+    s1clash = uni((int)s1clash) != 0;
+    have = uni((int)have) != 0;
+    hop_exact = uni((int)hop_exact) != 0;
+    cutoff = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cutoff)));
+
+    bool moved = false;  // the LDS beam changed in this iteration: positions and the window are stale
+    if (WANN_LIKELY(have)) {
+      // ---- the hop in flight: distances (beamSearch.h:135-145); what passes joins the pending candidates
+      const float dist = mid_take_distances<METRIC>(ix, a, kept, row_off, L.qv, mode, rr, sc_r, sc_nt);
+      const bool pass = kept && (dist < cutoff);
+      const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
+      const u64 pm = ballot64(pass);
+      WANN_PHASE(0);  // vectors + distances
+      if (WANN_UNLIKELY(hop_exact)) {
+        // (lanes of this row shared a filter slot -- the row may list a node twice, and then the multiset union keeps two copies:
+        // this hop's candidates are united on their own)
+        unite_pending();
+        int p0;
+        M = wave_merge(mb, M, B, pass, key, L.cand_key, &p0);
+        scan_from = p0 < scan_from ? p0 : scan_from;
+        set_cutoff();
+        moved = true;
+      } else if (pm) {
+        const int c = popc64(pm);
+        if (WANN_UNLIKELY(D + c > 64)) {
+          unite_pending();
+          moved = true;
+        }
+        if (pass) pend[D + popc64(pm & lanemask_lt())] = key;
+        D += c;
+        for (u64 mm = pm; mm; mm &= mm - 1) {
+          const u64 kc = rdlane64(key, ctz64(mm)) | 1ull;
+          pmin = kc < pmin ? kc : pmin;
+        }
+      }
+      WANN_PHASE(2);  // pending / union
+      // (a row that was requested behind these vectors is back with them: its probes can go out now)
+      if (s1n >= 0 && !s1probe) {
+        prepare(s1a, s1loc, s1clash);
+        s1old = gtable[s1loc];
+        s1probe = true;
+      }
+    }
+    // ---- The next hop visits s1 -- the first unvisited entry of the LDS beam -- unless a pending candidate sorts at or before
+    //      it (an equal key is a copy of s1's entry).  Then s1 is the closest unvisited entry of the whole beam and lies within
+    //      its first B entries: s1's rank is its position.
+    if (WANN_LIKELY(have && !moved && s1n >= 0 && nvis < lim && pmin > (s1k | 1ull))) {
+      if (lane == 0) mb[s1p] = s1k | 1ull;
+      wum &= ~((u64)1 << (s1p - wbase));
+      nvis++;
+      pos_c = s1p;
+      scan_from = s1p + 1;
+      a = s1a;
+      kept = filter(s1a, s1loc, s1old, s1clash);
+      hop_exact = s1clash;
+      if (prof) acc[5]++;
+    } else {
+      // ---- exact beam first; then the closest unvisited entry (beamSearch.h:108-117): entries before scan_from are visited
+      unite_pending();
+      WANN_PHASE(2);
+      if (nvis >= lim) break;
+      int cur = -1;
+      u64 ck = 0;
+      for (int sp = scan_from; sp < M; sp += 64) {
+        const int x = sp + lane;
+        const u64 e = x < M ? mb[x] : 1ull;
+        const u64 um = ballot64(!(e & 1ull));
+        if (um) {
+          const int i = ctz64(um);
+          ck = rdlane64(e, i);
+          cur = (int)((uint32_t)ck >> 1);
+          pos_c = sp + i;
+          break;
+        }
+      }
+      cur = uni(cur);
+      pos_c = uni(pos_c);
+      if (cur < 0) break;
+      if (lane == 0) mb[pos_c] = ck | 1ull;
+      nvis++;
+      scan_from = pos_c + 1;
+      // row and probes: on hand if this is an expected node (probes: only s1's, and only if no other hop's stores followed them)
+      uint32_t loc;
+      int old;
+      bool clash;
+      if (cur == s1n) {
+        a = s1a;
+        if (s1probe) {
+          loc = s1loc;
+          old = s1old;
+          clash = s1clash;
+        } else {
+          prepare(a, loc, clash);
+          old = gtable[loc];
+        }
+      } else {
+        a = (cur == s2n) ? s2a : load_row(cur);
+        prepare(a, loc, clash);
+        old = gtable[loc];
+      }
+      kept = filter(a, loc, old, clash);
+      hop_exact = clash;
+      load_window(pos_c + 1);
+      WANN_PHASE(3);  // unexpected node / stale positions: union, scan, row, probes, filter
+    }
+    s1probe = false;  // (this hop's stores follow whatever probes are out)
+    WANN_PHASE(1);  // filter
+    // ---- the next two expected nodes, their rows, s1's probes; then this hop's vectors -- all requests of a hop go out together
+    expect();
+    WANN_PHASE(4);  // expectations, probes
+    mid_request_rows<METRIC>(ix, a, kept, row_off, mode, rr, sc_r, sc_nt);
+    have = true;
+    WANN_PHASE(6);  // vector requests
+  }
+#undef WANN_PHASE
+  for (int o = 32; o; o >>= 1) ncmp_v += __shfl_xor(ncmp_v, o);
+  if (prof && lane == 0)
+    for (int i = 0; i < 7; i++) atomicAdd(&prof[i], acc[i]);  // (5: hops committed without a union)
   m_out = M;
   nvis_out = nvis;
   ncmp_out = 1 + ncmp_v;

@@ -1958,7 +1958,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
   auto is_valid = [&](int arow) -> bool { return (arow >= 0) && (lane < degree_limit) && ((int64_t)arow != qid); };
   // filter slots of a row + the exact test "two valid lanes of the row share a filter slot" (see wave_beam_search_big)
   auto prepare = [&](int arow, uint32_t &loc, bool &clash) {
-    loc = (uint32_t)hash64_2((u64)(uint32_t)arow) & tmask;
+    loc = (uint32_t)hash64_2((u64)(uint32_t)arow) & (WANN_AB == 3 ? 1023u : tmask);  // (AB 3: timing experiment, wrong rows)
     const bool valid = is_valid(arow);
     const uint32_t mh = loc & mini_mask;
     if (valid) mini[mh] = lane;

@@ -156,3 +156,31 @@ def replay(mod, name, kind, tmpdir, max_cases=None):
         if max_cases and n >= max_cases:
             break
     return n, failures
+
+
+def ratio_cases():
+    """(fixture, ratio, beam, mult, window key) of tests/golden/ratio_golden.npz (generator: golden/make_ratio_golden.py)."""
+    data = np.load(os.path.join(GOLDEN, "ratio_golden.npz"))
+    for f in data.files:
+        if f.startswith("ids|"):
+            name, ratio, beam, mult, p = f[4:].split("|")
+            yield data, f[4:], name, float(ratio), int(beam), int(mult), p
+
+
+def replay_ratio(mod, tmpdir):
+    """The min_query_to_bucket_ratio fall-back (src/range_filter_tree.h:460-466) against what the real reference returned."""
+    failures, n, built = [], 0, {}
+    for data, key, name, ratio, beam, mult, p in ratio_cases():
+        if name not in built:
+            built[name] = build_index(mod, name, "VamanaRangeFilterTreeIndex", tmpdir)
+        idx, fx = built[name]
+        Q, W, K = fx["Q"], fx["W_" + p], int(fx["meta"][3])
+        qp = mod.QueryParams(K, beam, 1.35, 10_000_000, 10_000, mult, 10000, ratio, False)
+        ids, dists = idx.batch_search(Q, W, Q.shape[0], "optimized_postfilter", qp)
+        # (queries that fall back to fenwick_tree_search return merged lists: the reference's unstable sort-by-distance)
+        ctx = RowContext(fx["X"], fx["labels"], Q, W, metric_of(FIXTURES[name]))
+        ok, why = same_rows(data["ids|" + key], data["dists|" + key], ids, dists, True, ctx)
+        if not ok:
+            failures.append(f"{key}: {why}")
+        n += 1
+    return n, failures

@@ -209,6 +209,13 @@ def test_golden_reference_outputs(wa, gpu, tmp_path, name, kind):
     assert n > 0
 
 
+def test_golden_ratio_fallback(wa, gpu, tmp_path):
+    """min_query_to_bucket_ratio (src/range_filter_tree.h:460-466) against the REAL reference's rows (ratio_golden.npz)"""
+    n, failures = gu.replay_ratio(wa, tmp_path)
+    assert n == 48
+    assert not failures, "\n".join(failures[:10])
+
+
 @pytest.mark.parametrize("name", list(gu.FIXTURES))
 def test_golden_quirks(wa, gpu, tmp_path, name):
     idx, data = gu.build_index(wa, name, "VamanaRangeFilterTreeIndex", tmp_path)

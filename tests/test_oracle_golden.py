@@ -30,6 +30,18 @@ def test_oracle_quirks(oracle, tmp_path, name):
     assert np.array_equal(dists, data["dists|VamanaRangeFilterTreeIndex|overshoot"])
 
 
+def test_oracle_ratio_fallback_replays_reference_outputs(oracle, tmp_path):
+    """min_query_to_bucket_ratio (src/range_filter_tree.h:460-466): ratios 1 / 1.5 / 3 / 8, L2 and inner product"""
+    n, failures = gu.replay_ratio(oracle, tmp_path)
+    assert n == 48
+    assert not failures, "\n".join(failures[:10])
+    # the fixture does exercise the branch: a tight ratio changes rows against the no-ratio call of the same batch
+    data = next(gu.ratio_cases())[0]
+    fx, _ = gu.load("sift_l2")
+    assert not np.array_equal(data["ids|sift_l2|1.0|40|2|-3"], fx["ids|VamanaRangeFilterTreeIndex|optimized_postfilter|40|2|-3"]) or \
+        not np.array_equal(data["dists|sift_l2|1.0|40|2|-3"], fx["dists|VamanaRangeFilterTreeIndex|optimized_postfilter|40|2|-3"])
+
+
 def test_hash_and_bits(oracle):
     # parlay::hash64_2 known answers (splitmix64 finaliser) and the seen-filter size rule
     assert oracle.hash64_2(0) == 0

@@ -53,6 +53,39 @@ def test_oracle_equals_reference(oracle, ref, tmp_path, metric, gen, d, kind):
                     assert np.array_equal(ri, oi), (kind, p, method, beam, mult)
 
 
+@pytest.mark.parametrize("metric,gen,d", [("Euclidian", sift_like, 64), ("mips", unit_mixture, 100)])
+def test_oracle_ratio_fallback_equals_reference(oracle, ref, tmp_path, metric, gen, d):
+    """min_query_to_bucket_ratio (src/range_filter_tree.h:460-466): windows that are a small share of their smallest containing
+    bucket take fenwick_tree_search -- distances identical for every ratio, ids wherever no merged list is involved"""
+    n, nq = 2500, 60
+    g = gen(n, d, 77)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 13)
+    sfx = "FloatMips" if metric == "mips" else "FloatEuclidian"
+    cache = str(tmp_path) + "/"
+    with quiet_stdout():
+        ridx = getattr(ref, "VamanaRangeFilterTreeIndex" + sfx)(X, labels, 250, 2, ref.BuildParams(24, 48, 1.0, cache))
+    oidx = getattr(oracle, "VamanaRangeFilterTreeIndex" + sfx)(X, filter_values=labels, cutoff=250, split_factor=2,
+                                                               build_params=oracle.BuildParams(24, 48, 1.0, cache))
+    changed = 0
+    for p in (-5, -3, -1):
+        W = windows(labels, nq, p, 90 + p)
+        base = None
+        for ratio in (None, 1.0, 1.5, 3.0, 8.0):
+            for beam, mult in [(10, 1), (40, 2)]:
+                with quiet_stdout():
+                    ri, rd = ridx.batch_search(Q, W, nq, "optimized_postfilter", ref.QueryParams(10, beam, 1.35, 10**7, 10**4, mult, 10000, ratio, False))
+                oi, od = oidx.batch_search(Q, W, nq, "optimized_postfilter", oracle.QueryParams(10, beam, 1.35, 10**7, 10**4, mult, 10000, ratio, False))
+                assert np.array_equal(rd, od), (p, ratio, beam, mult)
+                if gen is not sift_like:  # (integer data: merged lists hold distance ties the reference orders arbitrarily)
+                    assert np.array_equal(ri, oi), (p, ratio, beam, mult)
+                if ratio is None and (beam, mult) == (40, 2):
+                    base = rd
+                elif (beam, mult) == (40, 2) and not np.array_equal(base, rd):
+                    changed += 1
+    assert changed > 0  # some ratio did send queries down the other branch
+
+
 @pytest.mark.parametrize("metric,n,d,R,L", [("Euclidian", 1500, 16, 16, 40), ("mips", 3000, 24, 12, 32), ("Euclidian", 9000, 16, 8, 20)])  # L2: d % 8 == 0 (the reference reads past d otherwise, SURVEY 8 a11)
 def test_oracle_builder_equals_reference_builder(oracle, ref, tmp_path, metric, n, d, R, L):
     """Whole tree of graphs (every partition size down to the leaves) on continuous coordinates: every cache

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,6 +70,7 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
 constexpr int kInts = 160;
 enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_POLL_WAITING = 146, I_PRIO_COUNT = 147, I_SCAN_COUNT = 148, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
 constexpr int kMaxRounds = 30;
+constexpr int kVlogCap = 24;  // QueryParams::verbose: records per task (a doubling loop from beam 1 to 2^20 is 21 searches + the final one)
 
 struct Workspace {
   DevBuf<Task> tasks;
@@ -161,8 +163,9 @@ struct wann_index {
   DevBuf<float> d_pnorm2;
   DevBuf<unsigned int> d_pnorm2_max;
   bool have_norms = false;
-  int dense_idle = 0;            // batches in a row on which the dense path found no window group (run_batch)
-  uint32_t dense_batches = 0;
+  // (touched by the blocking calls and by both asynchronous lanes, outside dense_mu for every class but PrefilterIndex)
+  std::atomic<int> dense_idle{0};  // batches in a row on which the dense path found no window group (run_batch)
+  std::atomic<uint32_t> dense_batches{0};
   DevBuf<GemmGroup> g_groups;
   DevBuf<int32_t> g_gq, g_tile_group, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan;
   DevBuf<unsigned long long> g_slot_key, g_score_used;
@@ -172,7 +175,10 @@ struct wann_index {
   hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
   wann_counters last{};
   // every WANN_* switch, read when the index is created (wann_tuning.h); run_batch never reads the environment
+  // (a call works on a COPY taken under tune_mu -- snapshot_tuning: with WANN_TEST_HOOKS=1 the entry points re-read the record
+  // while a lane's worker may still be inside a batch)
   Tuning tune;
+  std::mutex tune_mu;
   std::mutex mu;
   std::mutex dense_mu;  // the dense prefilter path's buffers and counters belong to the index: one batch at a time uses them
   // wann_batch_search_device_async: further LANES -- a lane is everything one batch in flight needs (workspace, streams, a
@@ -181,12 +187,21 @@ struct wann_index {
   std::unique_ptr<Rccl> rccl;
   struct AsyncLane;
   std::vector<std::unique_ptr<AsyncLane>> lanes;
-  std::mutex lanes_mu;
+  std::mutex lanes_mu;   // lanes, next_ticket (held briefly)
+  std::mutex gather_mu;  // wann_batch_search_allgather: RCCL set-up, the replicas' send / receive planes and the collective, one call at a time
+  std::mutex submit_mu;  // one submission at a time (held while a submitter waits for its lane to fall idle)
   int64_t next_ticket = 0;
   ~wann_index();
 };
 
 namespace {
+
+// the index's switches for one call (WANN_TEST_HOOKS=1: re-read from the environment first)
+Tuning snapshot_tuning(wann_index &I) {
+  std::lock_guard<std::mutex> lk(I.tune_mu);
+  if (I.tune.hooks_live) I.tune = Tuning::from_env();
+  return I.tune;
+}
 
 void upload_index(wann_index &I) {
   HostIndex &H = I.host();
@@ -351,7 +366,7 @@ struct RoundCfg {
 constexpr int kLdsGranule = 1280, kLdsPerCu = 160 * 1024;
 inline int lds_blocks_per_cu(int per_block) { return kLdsPerCu / (((per_block + kLdsGranule - 1) / kLdsGranule) * kLdsGranule); }
 
-RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false,
+RoundCfg config_for(const wann_index &I, const Tuning &T, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false,
                     bool legacy = false, int base_pool = kSearchPoolBytes) {
   RoundCfg rc{};
   const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
@@ -379,7 +394,7 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
   const int waves_per_cu = (I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32) ? 12 : 8;
   int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, lds_blocks_per_cu(per_block));
   blocks_per_cu = std::max(1, blocks_per_cu);
-  if (I.tune.blocks_per_cu > 0) blocks_per_cu = std::max(1, std::min(blocks_per_cu, I.tune.blocks_per_cu));  // dev knob
+  if (T.blocks_per_cu > 0) blocks_per_cu = std::max(1, std::min(blocks_per_cu, T.blocks_per_cu));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
   const int cap_bits = hash_bits(cap);
   if (force_table || cap_bytes + ((int64_t)4 << cap_bits) > usable) {  // some beam of the range keeps its filter in global memory
@@ -402,14 +417,14 @@ RoundCfg config_for(const wann_index &I, int64_t first_beam, int64_t cap, int64_
 // Per-wave pool with which THREE four-wave workgroups share a CU's 160 KiB of LDS (inner-product / byte-row kernels, which
 // fit three waves per SIMD): the in-kernel cap's beam (10 KiB) still fits, the seen-filter of beams up to 90 too.  0: this
 // index can not use it (rows too long).
-int lean_pool_bytes(const wann_index &I) {
+int lean_pool_bytes(const wann_index &I, const Tuning &T) {
   if (!(I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32)) return 0;
   const int common = search_lds_bytes_per_wave(I.view.stride, 0);
   // 52 KiB per workgroup.  Three workgroups of 53 KiB (159 of the CU's 160 KiB) are NOT co-resident on gfx950, whatever
   // hipOccupancyMaxActiveBlocksPerMultiprocessor says (3): a launch of 768 such workgroups ran at the speed of 512 until round 4
   // measured it (stand-alone inner-product graph, 30 000 searches at beam 80: 6.65 ms at 53 KiB, 5.22 ms at 52.5 KiB and below).
   int pool = (52 * 1024) / kWavesPerBlock - common;
-  if (I.tune.lean_pool > 0) pool = I.tune.lean_pool;  // dev knob
+  if (T.lean_pool > 0) pool = T.lean_pool;  // dev knob
   return pool >= kInKernelBeamCap * 8 + 1536 ? pool : 0;
 }
 
@@ -424,7 +439,7 @@ int method_code(const char *m) {
 // every query whose top-k cannot be proven from the MFMA scores) goes through the exact scan kernel.  Grouping,
 // tile planning and the hand-over to the exact scan all happen on the device: the host enqueues six launches and
 // never waits.
-void dense_prefilter(wann_index &I, Workspace &W, const float *d_queries, int64_t nq, int k, hipStream_t st) {
+void dense_prefilter(wann_index &I, const Tuning &T, Workspace &W, const float *d_queries, int64_t nq, int k, hipStream_t st) {
   if (k > kSelect / 2 || I.view.stride > 512 || (I.view.stride & 15)) return;  // (rows of up to 512 floats: RedCaps)
   if (!I.have_norms) {
     I.d_pnorm2.ensure((size_t)I.view.n);
@@ -481,7 +496,7 @@ void dense_prefilter(wann_index &I, Workspace &W, const float *d_queries, int64_
   // additions, u = 2^-24 with a rounding adder, 2^-23 with a truncating one; 3 = the truncating bound and half as much again.
   // (Round 2 used 8: at d = 512 that one term was 7.4e-4 |q||p|, 46 % of the adversarial queries could not be proven.)
   // The knob can only widen the margin (Tuning clamps it to >= 3): a smaller factor would certify unproven results.
-  ga.acc_factor = I.tune.proof_factor;
+  ga.acc_factor = T.proof_factor;
   ga.out_key = W.out_key.p;
   ga.out_cnt = W.out_cnt.p;
   ga.brute_list = W.list_brute.p;
@@ -504,7 +519,7 @@ void dense_prefilter(wann_index &I, Workspace &W, const float *d_queries, int64_
 
 // W / side / last: the lane of this batch (the index's own members for the blocking calls, an AsyncLane's for the asynchronous one)
 void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &last, const float *d_queries, const float *d_ranges, int64_t nq,
-               int64_t qid_base, const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st) {
+               int64_t qid_base, const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st, const Tuning &T) {
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
   // the brute-force classes ignore the beam (the reference driver passes beam_size = 0 there, run_our_method.py:256)
   if (qp.beam_width <= 0 && I.host().vamana_leaves) throw std::runtime_error("beam_width must be positive");
@@ -520,7 +535,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   // multi-bucket fenwick cover, which cannot happen for split <= 4 without a ratio: SURVEY.md A.5)
   const bool single = !tree || (mcode == M_OPTIMIZED && !qp.has_min_query_to_bucket_ratio && I.host().spec.split_factor <= 4);
   const int maxt = single ? 1 : 96;
-  const Tuning &T = I.tune;
+  // (T: this call's copy of the index's switches -- snapshot_tuning)
   // QueryParams::verbose (postfilter_vamana.h:155-185,230): the doubling loop of every (query, partition) search is dumped to
   // stdout in the reference's words after the batch -- a debugging aid: such a call runs plain sequential doubling in the
   // one-wave legacy kernel, which records every search
@@ -606,7 +621,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   bool tried_dense = false;
   if (I.host().spec.kind == WANN_KIND_PREFILTER && nq >= 32 && I.host().spec.dtype == WANN_DTYPE_F32 && T.gemm &&
       (I.dense_idle < 2 || (I.dense_batches & 7) == 0 || T.dense_always)) {
-    dense_prefilter(I, W, d_queries, nq, k, st);
+    dense_prefilter(I, T, W, d_queries, nq, k, st);
     tried_dense = true;
   }
   I.dense_batches++;
@@ -667,7 +682,6 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     sa.max_beam = (int32_t)qp.postfiltering_max_beam;
     sa.pool_bytes = kSearchPoolBytes;
     sa.force_general = (T.force_general || I.view.rs > 64 || verbose_call) ? 1 : 0;  // (wide rows: the register-resident cores take 64 neighbours)
-    constexpr int kVlogCap = 24;
     if (verbose_call) {
       const size_t nt = (size_t)nq * maxt;
       W.vlog.ensure(nt * kVlogCap);
@@ -705,7 +719,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     const bool scan_on = spec && T.scan && T.lookahead;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0,
                       int base_pool = kSearchPoolBytes) {
-      RoundCfg rc = config_for(I, first_beam, cap, items, big_lds || verbose_call, a.force_general != 0, a.old_general != 0, base_pool);
+      RoundCfg rc = config_for(I, T, first_beam, cap, items, big_lds || verbose_call, a.force_general != 0, a.old_general != 0, base_pool);
       big_lds = rc.big_lds;
       a.big_list = nullptr;  // (the one-wave kernel then takes ordinary tickets)
       a.helper = (rc.lc.big == 1 && T.helper) ? kHelpers : 0;
@@ -870,7 +884,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     // Three workgroups per CU (a leaner LDS pool) where the kernel allows it and no companion workgroup has to share a CU with
     // the ordinary ones (the deep-chain pollers book whole CUs of their own)
     int base_pool = kSearchPoolBytes;
-    if (big_n == 0 && !may_continue && T.lean && cap1 == kInKernelBeamCap && lean_pool_bytes(I) > 0) base_pool = lean_pool_bytes(I);
+    if (big_n == 0 && !may_continue && T.lean && cap1 == kInKernelBeamCap && lean_pool_bytes(I, T) > 0) base_pool = lean_pool_bytes(I, T);
     // How many: with two workgroups per CU (squared-L2 float kernel) four -- 16 cost the SIFT-1M 2^-3 batch 2.5 %; with three
     // (twelve waves share a CU's memory path: a third level takes 2.2 ms there, 1.5 ms on a poller) every third-level chain
     // should find one: 16 (deep-10M-like, eight such chains: 5.3 -> 4.5 ms per batch; 12 ... 32 measure alike).
@@ -999,9 +1013,11 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   HIP_CHECK(hipStreamSynchronize(st));
 
   if (verbose_call && W.vlog.p) {
+    static std::mutex dump_mu;  // (WANN_DEVICES: one replica's dump at a time -- whole blocks, not interleaved lines)
+    std::lock_guard<std::mutex> dump_lock(dump_mu);
     // the reference's dump (postfilter_vamana.h:155-185 + :230), per query and partition search, in query order
     const size_t nt = (size_t)nq * maxt;
-    constexpr int cap_v = 24;
+    constexpr int cap_v = kVlogCap;
     std::vector<Task> ht(nt);
     std::vector<int32_t> hq((size_t)nq), hn(nt);
     std::vector<unsigned long long> hv(nt * cap_v);
@@ -1035,11 +1051,13 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
           if (frontier < qp.k) beam *= 2;
         }
         const long long fb = std::min<long long>(beam * mult, qp.postfiltering_max_beam);
-        if (fb > beam && e < ne) {  // :173-181
-          long long b_, m_, f_;
-          rec(e++, b_, m_, f_);
-          printf("Unfiltered return = %lld\n", m_);
-          frontier = f_;
+        if (fb > beam) {  // :173-181 (the final re-search; should its record be missing -- more searches than records -- the
+          if (e < ne) {   // line below still names the beam the reference would)
+            long long b_, m_, f_;
+            rec(e++, b_, m_, f_);
+            printf("Unfiltered return = %lld\n", m_);
+            frontier = f_;
+          }
           beam = fb;
         }
         printf("Final frontier size = %lld, final beam size %lld\n", frontier, beam);
@@ -1067,7 +1085,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   last.rounds = rounds;
   last.recovered_continuations = recovered;
   last.gemm_queries = (int64_t)W.h_ctr->gemm_queries;
-  if (tried_dense) I.dense_idle = W.h_ctr->gemm_queries ? 0 : I.dense_idle + 1;
+  if (tried_dense) I.dense_idle = W.h_ctr->gemm_queries ? 0 : I.dense_idle.load() + 1;
   last.gemm_unproven = (int64_t)W.h_ctr->gemm_unproven;
   last.gemm_rescued = (int64_t)W.h_ctr->gemm_rescued;
   last.deep_handoffs = (int64_t)W.h_ctr->deep_handoffs;
@@ -1173,6 +1191,7 @@ struct wann_index::AsyncLane {
     uint32_t *ids;
     float *dists;
     int64_t ticket;
+    Tuning tune;  // the index's switches as they were at submission (the worker never reads the index's record)
   };
   std::thread th;
   std::mutex m;
@@ -1197,7 +1216,7 @@ struct wann_index::AsyncLane {
       try {
         HIP_CHECK(hipSetDevice(I->device));
         HIP_CHECK(hipStreamWaitEvent(stream, ready, 0));
-        run_batch(*I, ws, side, last, j.q, j.r, j.nq, j.base, j.method.c_str(), j.qp, j.ids, j.dists, stream);
+        run_batch(*I, ws, side, last, j.q, j.r, j.nq, j.base, j.method.c_str(), j.qp, j.ids, j.dists, stream, j.tune);
       } catch (HipError &e) {
         code = WANN_ERR_HIP;
         msg = e.what();
@@ -1368,8 +1387,8 @@ int wann_batch_search_device(wann_index *I, const void *d_queries, const float *
     // NULL = the HIP default stream: ordered after everything the caller queued on its default stream
     // (torch's current stream unless changed), so freshly produced inputs / recycled output blocks are safe
     hipStream_t st = (hipStream_t)hip_stream;
-    if (I->tune.hooks_live) I->tune = Tuning::from_env();  // WANN_TEST_HOOKS=1 only: tests flip switches between batches
-    run_batch(*I, I->ws, I->side_stream, I->last, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st);
+    const Tuning T = snapshot_tuning(*I);  // (WANN_TEST_HOOKS=1 only: tests flip switches between batches)
+    run_batch(*I, I->ws, I->side_stream, I->last, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st, T);
   } catch (HipError &e) {
     return fail(WANN_ERR_HIP, e.what());
   } catch (std::exception &e) {
@@ -1386,30 +1405,46 @@ int wann_batch_search_device_async(wann_index *I, const void *d_queries, const f
                                    int64_t *ticket) {
   if (!I || !qp || nq < 0 || !ticket) return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_device_async");
   try {
-    std::lock_guard<std::mutex> lk(I->lanes_mu);
+    // One submission at a time; lanes_mu (which wann_wait takes too) is only held to look at / publish the lane table and the
+    // ticket counter, never while this call waits for its lane to fall idle.
+    std::lock_guard<std::mutex> sub(I->submit_mu);
     HIP_CHECK(hipSetDevice(I->device));
-    if (I->tune.hooks_live) I->tune = Tuning::from_env();
-    if (I->lanes.empty())
-      for (int l = 0; l < kAsyncLanes; l++) {
-        std::unique_ptr<wann_index::AsyncLane> L(new wann_index::AsyncLane);
-        int prio_low = 0, prio_high = 0;
-        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        HIP_CHECK(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithPriority(&L->side, hipStreamNonBlocking, prio_high));
-        HIP_CHECK(hipEventCreateWithFlags(&L->ready, hipEventDisableTiming));
-        wann_index::AsyncLane *lp = L.get();
-        L->th = std::thread([lp, I] { lp->loop(I); });
-        I->lanes.push_back(std::move(L));
+    const Tuning tune = snapshot_tuning(*I);
+    int64_t t;
+    wann_index::AsyncLane *Lp;
+    {
+      std::lock_guard<std::mutex> lk(I->lanes_mu);
+      if (I->lanes.empty()) {
+        // (all lanes or none: a lane table that a failed creation left half filled would be indexed out of bounds by odd tickets)
+        std::vector<std::unique_ptr<wann_index::AsyncLane>> fresh;
+        for (int l = 0; l < kAsyncLanes; l++) {
+          std::unique_ptr<wann_index::AsyncLane> L(new wann_index::AsyncLane);
+          int prio_low = 0, prio_high = 0;
+          HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+          HIP_CHECK(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+          HIP_CHECK(hipStreamCreateWithPriority(&L->side, hipStreamNonBlocking, prio_high));
+          HIP_CHECK(hipEventCreateWithFlags(&L->ready, hipEventDisableTiming));
+          wann_index::AsyncLane *lp = L.get();
+          L->th = std::thread([lp, I] { lp->loop(I); });
+          fresh.push_back(std::move(L));
+        }
+        I->lanes.swap(fresh);
       }
-    const int64_t t = I->next_ticket++;
-    wann_index::AsyncLane &L = *I->lanes[(size_t)(t % kAsyncLanes)];
+      t = I->next_ticket;
+      Lp = I->lanes[(size_t)(t % kAsyncLanes)].get();
+    }
+    wann_index::AsyncLane &L = *Lp;
     {
       std::unique_lock<std::mutex> ll(L.m);
       L.cv.wait(ll, [&] { return !L.busy; });  // (ticket t - kAsyncLanes has finished; wann_wait it BEFORE submitting this one to see its outcome)
       HIP_CHECK(hipEventRecord(L.ready, (hipStream_t)after_stream));
-      L.job = wann_index::AsyncLane::Job{(const float *)d_queries, d_ranges, nq, query_id_base, method ? method : "", *qp, d_ids, d_dists, t};
+      L.job = wann_index::AsyncLane::Job{(const float *)d_queries, d_ranges, nq, query_id_base, method ? method : "", *qp, d_ids, d_dists, t, tune};
       L.has_job = true;
       L.busy = true;
+    }
+    {  // the ticket exists from here on (a submission that failed above took none)
+      std::lock_guard<std::mutex> lk(I->lanes_mu);
+      I->next_ticket = t + 1;
     }
     L.cv.notify_all();
     *ticket = t;
@@ -1464,6 +1499,9 @@ int wann_batch_search_allgather(wann_index *I, const void *queries, const float 
   for (int a = 0; a < G; a++)
     for (int b = a + 1; b < G; b++)
       if (devs[a] == devs[b]) return fail(WANN_ERR_UNSUPPORTED, "wann_batch_search_allgather needs DISTINCT devices in WANN_DEVICES (one RCCL rank per device)");
+  // (one call at a time: the communicators are created lazily, and the planes of a replica's workspace are read by the collective
+  // after that replica's own mutex has been released)
+  std::lock_guard<std::mutex> gather_lock(I->gather_mu);
   try {
     if (!I->rccl) {
       std::unique_ptr<wann_index::Rccl> r(new wann_index::Rccl);
@@ -1485,7 +1523,7 @@ int wann_batch_search_allgather(wann_index *I, const void *queries, const float 
         try {
           std::lock_guard<std::mutex> lk(T->mu);
           HIP_CHECK(hipSetDevice(T->device));
-          if (T->tune.hooks_live) T->tune = Tuning::from_env();
+          const Tuning tune = snapshot_tuning(*T);
           Workspace &W = T->ws;
           hipStream_t st = T->own_stream;
           W.gat_send.ensure((size_t)(2 * cap * k));
@@ -1508,7 +1546,7 @@ int wann_batch_search_allgather(wann_index *I, const void *queries, const float 
             HIP_CHECK(hipMemsetAsync(ids_plane + cnt * k, 0, (size_t)((cap - cnt) * k) * 4, st));
             HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(dist_plane + cnt * k), 0x7f7fffff, (size_t)((cap - cnt) * k), st));
           }
-          run_batch(*T, W, T->side_stream, T->last, W.q_stage.p, W.r_stage.p, cnt, lo, method, *qp, (uint32_t *)ids_plane, (float *)dist_plane, st);
+          run_batch(*T, W, T->side_stream, T->last, W.q_stage.p, W.r_stage.p, cnt, lo, method, *qp, (uint32_t *)ids_plane, (float *)dist_plane, st, tune);
         } catch (HipError &e) {
           codes[(size_t)g] = WANN_ERR_HIP;
           errs[(size_t)g] = e.what();
@@ -1524,12 +1562,23 @@ int wann_batch_search_allgather(wann_index *I, const void *queries, const float 
     // one all-gather of the [2][cap][k] planes, all replicas in one group call
     wann_index::Rccl &N = *I->rccl;
     N.check(N.GroupStart(), "ncclGroupStart");
-    for (int g = 0; g < G; g++) {
-      wann_index *T = reps[(size_t)g];
-      HIP_CHECK(hipSetDevice(T->device));
-      N.check(N.AllGather(T->ws.gat_send.p, T->ws.gat_recv.p, (size_t)(2 * cap * k), ncclInt32, N.comms[(size_t)g], T->own_stream), "ncclAllGather");
+    {
+      // (an open group is always closed: a failing call between the two would leave the communicators unusable)
+      struct GroupGuard {
+        wann_index::Rccl &n;
+        bool open = true;
+        ~GroupGuard() {
+          if (open) (void)n.GroupEnd();
+        }
+      } guard{N};
+      for (int g = 0; g < G; g++) {
+        wann_index *T = reps[(size_t)g];
+        HIP_CHECK(hipSetDevice(T->device));
+        N.check(N.AllGather(T->ws.gat_send.p, T->ws.gat_recv.p, (size_t)(2 * cap * k), ncclInt32, N.comms[(size_t)g], T->own_stream), "ncclAllGather");
+      }
+      guard.open = false;
+      N.check(N.GroupEnd(), "ncclGroupEnd");
     }
-    N.check(N.GroupEnd(), "ncclGroupEnd");
     for (int g = 0; g < G; g++) {
       wann_index *T = reps[(size_t)g];
       HIP_CHECK(hipSetDevice(T->device));
@@ -1563,6 +1612,7 @@ int wann_predict_costs(wann_index *I, const float *ranges, int64_t nq, const cha
     W.ensure(nq, k, maxt, 0);
     W.r_stage.ensure((size_t)nq * 2);
     W.dist_stage.ensure((size_t)nq);
+    const Tuning tune = snapshot_tuning(*I);
     hipStream_t st = I->own_stream;
     HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
@@ -1587,12 +1637,12 @@ int wann_predict_costs(wann_index *I, const float *ranges, int64_t nq, const cha
     ra.heavy_cap = W.big_stride;
     ra.mid_list = W.list_mid.p;
     ra.mid_count = W.ints.p + I_MID_COUNT;
-    ra.heavy_ratio = I->tune.heavy_ratio;
+    ra.heavy_ratio = tune.heavy_ratio;
     ra.risk_count = W.ints.p + I_RISK;
     ra.brute_list = W.list_brute.p;
     ra.brute_count = W.ints.p + I_BRUTE_COUNT;
     ra.spec = 0;  // (plain tasks only: each carries its window's size)
-    ra.spec_num = I->tune.spec_num;
+    ra.spec_num = tune.spec_num;
     ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp->beam_width);
     ra.sub_base0 = ra.sub_cap = (int32_t)(nq * maxt);
     ra.sub_count = W.ints.p + I_SUB_COUNT;
@@ -1629,7 +1679,7 @@ void search_host_one(wann_index &T, const void *queries, const float *ranges, in
                      const wann_query_params &qp, uint32_t *ids, float *dists) {
   std::lock_guard<std::mutex> lk(T.mu);
   HIP_CHECK(hipSetDevice(T.device));
-  if (T.tune.hooks_live) T.tune = Tuning::from_env();  // WANN_TEST_HOOKS=1 only
+  const Tuning tune = snapshot_tuning(T);  // (WANN_TEST_HOOKS=1 only: re-read)
   Workspace &W = T.ws;
   const int64_t d = T.host().spec.d;
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
@@ -1647,7 +1697,7 @@ void search_host_one(wann_index &T, const void *queries, const float *ranges, in
     HIP_CHECK(hipMemcpyAsync(W.q_stage.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
   }
-  run_batch(T, W, T.side_stream, T.last, W.q_stage.p, W.r_stage.p, nq, qid_base, method, qp, W.id_stage.p, W.dist_stage.p, st);
+  run_batch(T, W, T.side_stream, T.last, W.q_stage.p, W.r_stage.p, nq, qid_base, method, qp, W.id_stage.p, W.dist_stage.p, st, tune);
   if (nq) {
     HIP_CHECK(hipMemcpyAsync(ids, W.id_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(dists, W.dist_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));
@@ -1875,7 +1925,7 @@ struct RawGraph {
     // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
     // (dev: WANN_LEAN_POOL under WANN_TEST_HOOKS=1 gives the raw search the leaner per-wave pool too -- three workgroups per CU)
     const int raw_pool = (T.hooks_live && T.lean_pool > 0) ? T.lean_pool : kSearchPoolBytes;
-    RoundCfg rc = config_for(I, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general, raw_pool);
+    RoundCfg rc = config_for(I, T, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general, raw_pool);
     SearchArgs sa{};
     sa.ix = I.view;
     sa.queries = d_q.p;

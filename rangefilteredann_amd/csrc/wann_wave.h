@@ -1748,7 +1748,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
 // (NR = the most blocks a lane holds: what the kernel's register budget affords -- 16 in the squared-L2 float kernel (two waves
 // per SIMD), fewer or none in the kernels built for three)
 #if WANN_DT != 0
-constexpr int kRowRegs = 8;  // byte rows of up to 256 elements
+constexpr int kRowRegs = 4;  // byte rows of up to 128 elements (8 cost the byte kernels, built for three waves per SIMD, a scratch segment)
 #else
 constexpr int kRowRegsL2 = 16, kRowRegsMips = 0;
 #endif
@@ -1958,7 +1958,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
   auto is_valid = [&](int arow) -> bool { return (arow >= 0) && (lane < degree_limit) && ((int64_t)arow != qid); };
   // filter slots of a row + the exact test "two valid lanes of the row share a filter slot" (see wave_beam_search_big)
   auto prepare = [&](int arow, uint32_t &loc, bool &clash) {
-    loc = (uint32_t)hash64_2((u64)(uint32_t)arow) & (WANN_AB == 3 ? 1023u : tmask);  // (AB 3: timing experiment, wrong rows)
+    loc = (uint32_t)hash64_2((u64)(uint32_t)arow) & tmask;
     const bool valid = is_valid(arow);
     const uint32_t mh = loc & mini_mask;
     if (valid) mini[mh] = lane;
@@ -1981,8 +1981,11 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     const int tagged = (int)(tag | (uint32_t)arow);
     bool seen;
     if (WANN_LIKELY(!clash)) {
+      // (a slot that holds this id already is left alone: the store would change nothing, and its line -- one 128-byte line of
+      // HBM per neighbour: the filter of a beam-1 280 search is 2 MiB -- need not be written back.  Under load these searches
+      // are bound by such traffic, not by latency: half of what a hop moves is filter lines.)
       seen = valid && (old == tagged);
-      if (valid) gtable[loc] = tagged;
+      if (valid && !seen) gtable[loc] = tagged;
     } else {  // exact emulation: the nearest preceding lane of the same slot, else the table; the last lane of a slot class stores
       u64 eq = ballot64(valid);
       for (int b = 0; b < bits; b++) {

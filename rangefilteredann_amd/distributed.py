@@ -41,13 +41,15 @@ def shard_capacity(nq: int, world: int) -> int:
 
 def weighted_bounds(costs: Sequence[float], world: int) -> List[Tuple[int, int]]:
     """`world` contiguous shards [lo, hi) of about equal total cost: shard r ends at the first query whose prefix sum reaches
-    (r + 1) / world of the total.  Every shard gets at least one query while there are queries left for the shards after it;
-    with nq < world the last shards are empty.  Deterministic: float64 prefix sums of the given costs."""
+    (r + 1) / world of the total.  Every shard gets at least one query while there are queries left -- so with nq < world the
+    FIRST nq shards hold one query each and the last ones are empty.  Deterministic: float64 prefix sums of the given costs."""
     import numpy as np
     c = np.maximum(np.asarray(costs, dtype=np.float64), 0.0)
     nq = int(c.shape[0])
     if nq == 0:
         return [(0, 0)] * world
+    if nq < world:  # one query each for the first nq shards
+        return [(r, r + 1) for r in range(nq)] + [(nq, nq)] * (world - nq)
     pre = np.cumsum(c)
     total = float(pre[-1])
     if not total > 0.0:
@@ -59,8 +61,7 @@ def weighted_bounds(costs: Sequence[float], world: int) -> List[Tuple[int, int]]
         else:
             hi = int(np.searchsorted(pre, total * (r + 1) / world, side="left")) + 1  # the query that crosses the target stays in r
             hi = max(hi, lo + 1)                   # at least one query ...
-            hi = min(hi, nq - (world - 1 - r))     # ... and one left for each shard after this one (when there are enough)
-            hi = max(hi, lo)
+            hi = min(hi, nq - (world - 1 - r))     # ... and one left for each shard after this one
         hi = min(hi, nq)
         bounds.append((lo, hi))
         lo = hi

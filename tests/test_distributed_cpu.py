@@ -100,6 +100,8 @@ def test_weighted_bounds_balance_and_cover():
                 assert all(b[i][1] == b[i + 1][0] for i in range(world - 1)) and all(hi >= lo for lo, hi in b)
                 if nq >= world:
                     assert all(hi > lo for lo, hi in b), (nq, world, law, b)
+                else:  # fewer queries than shards: the FIRST nq shards hold one query each, the rest are empty
+                    assert b == [(r, r + 1) for r in range(nq)] + [(nq, nq)] * (world - nq), (nq, world, law, b)
                 if nq and law in ("flat", "skewed"):  # no shard carries more than its share plus one query's cost
                     tot, mx = float(c.sum()), float(c.max())
                     assert max(float(c[lo:hi].sum()) for lo, hi in b) <= tot / world + mx + 1e-9

@@ -439,35 +439,43 @@ def main():
     # the asynchronous call (two batches in flight: batch i + 1 is routed and ramps up under batch i's tail) over the same rotating
     # batches -- beside `value` (the reference's protocol is one blocking call per batch), never as `value`
     pipe = None
-    if rank == 0 and world == 1 and args.pipeline >= 2:
-        depth = min(args.pipeline, 2)
-        pouts = [(torch.empty((nq, K), dtype=torch.int32, device=dev), torch.empty((nq, K), dtype=torch.float32, device=dev)) for _ in range(depth + 1)]
+    pouts = None
 
-        def pipelined(nsteps):
+    def pipelined_rate(qs, ws, qp_, nsteps, warm, ref_rows=None):
+        """`nsteps` batches (rotating through qs / ws) through the asynchronous call, two in flight; optionally the rows of one more
+        qs[0] / ws[0] batch against `ref_rows` (the blocking call's)."""
+        depth = 2
+
+        def go(ns):
             tickets, ctrs = [], []
-            for i in range(nsteps):
+            for i in range(ns):
                 oi, od = pouts[i % len(pouts)]
-                tickets.append(index.batch_search_device_async(rot_q[i % rot].data_ptr(), rot_w[i % rot].data_ptr(), nq, lo, method, qp_run,
+                tickets.append(index.batch_search_device_async(qs[i % len(qs)].data_ptr(), ws[i % len(ws)].data_ptr(), nq, lo, method, qp_,
                                                                oi.data_ptr(), od.data_ptr(), 0))
-                if i >= depth - 1 and i - (depth - 1) >= 0 and len(tickets) > depth - 1:
+                if i >= depth - 1:
                     ctrs.append(index.wait(tickets[i - (depth - 1)]))
             for t in tickets[len(ctrs):]:
                 ctrs.append(index.wait(t))
             return ctrs
         torch.cuda.synchronize()
-        pipelined(max(2, args.warmup))
+        go(max(2, warm))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        pc = pipelined(args.steps)
+        pc = go(nsteps)
         torch.cuda.synchronize()
         pel = time.perf_counter() - t1
-        p_bytes = sum(4 * (R + 1) * c["hops"] + d * 4 * c["dist_cmps"] + 4 * c["label_reads"] for c in pc)
-        # rows of one more rotation-0 batch through the asynchronous call against the blocking call's
-        index.wait(index.batch_search_device_async(rot_q[0].data_ptr(), rot_w[0].data_ptr(), nq, lo, method, qp_run, pouts[0][0].data_ptr(), pouts[0][1].data_ptr(), 0))
-        same = bool((pouts[0][0] == all_ids[lo:hi]).all().item()) and bool((pouts[0][1] == all_d[lo:hi]).all().item())
-        pipe = dict(in_flight=depth, qps=round(nq * args.steps / pel, 1), ms_per_step=round(pel / args.steps * 1e3, 4),
-                    hbm_frac_of_wall=round(p_bytes / pel / 1e9 / HBM_PEAK_GBS, 4), rows_equal_blocking_call=same)
-        log(f"pipelined ({depth} in flight): {pipe}")
+        p_bytes = sum(4 * (R + 1) * c["hops"] + d * 4 * (c["dist_cmps"] + c["brute_rows"]) + 4 * c["label_reads"] for c in pc)
+        rec = dict(in_flight=depth, qps=round(nq * nsteps / pel, 1), ms_per_step=round(pel / nsteps * 1e3, 4),
+                   hbm_frac_of_wall=round(p_bytes / pel / 1e9 / HBM_PEAK_GBS, 4))
+        if ref_rows is not None:
+            index.wait(index.batch_search_device_async(qs[0].data_ptr(), ws[0].data_ptr(), nq, lo, method, qp_, pouts[0][0].data_ptr(), pouts[0][1].data_ptr(), 0))
+            rec["rows_equal_blocking_call"] = bool((pouts[0][0] == ref_rows[0]).all().item()) and bool((pouts[0][1] == ref_rows[1]).all().item())
+        return rec
+
+    if rank == 0 and world == 1 and args.pipeline >= 2:
+        pouts = [(torch.empty((nq, K), dtype=torch.int32, device=dev), torch.empty((nq, K), dtype=torch.float32, device=dev)) for _ in range(3)]
+        pipe = pipelined_rate([q[lo:hi] for q in rot_q], [w[lo:hi] for w in rot_w], qp_run, args.steps, args.warmup, (all_ids[lo:hi], all_d[lo:hi]))
+        log(f"pipelined (2 in flight): {pipe}")
 
     # the reference's own boundary (numpy in, numpy out): the same batch through the host-buffer entry point,
     # PCIe copies included -- reported beside `value`, never as `value`
@@ -561,6 +569,13 @@ def main():
                                  # over the WHOLE call's device time, against the 8 TB/s HBM peak
                                  algorithmic_gb=round(b["alg_bytes"] / 1e9, 3),
                                  roofline_frac=round(b["alg_bytes"] / (b["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b["device_ms"] > 0 else None)
+            if pouts is not None and p in (-9, -6):
+                # do two batches in flight buy anything where a batch ends with a few long chains?  (rows against the blocking call's)
+                run(Wpt[lo:hi], b["beam"], b["mult"])
+                blocking = (ids_t.clone(), dist_t.clone())
+                pr = pipelined_rate([Qt], [Wpt[lo:hi]], qparams(wa, b["beam"], b["mult"]), 6, 2, blocking)
+                pr["speedup_over_blocking"] = round(b["wall_ms"] / pr["ms_per_step"], 3)
+                per[f"2^{p}"]["pipelined"] = pr
             log(f"  2^{p}: {per[f'2^{p}']}")
             if want_ref:
                 run(Wpt[lo:hi], b["beam"], b["mult"])
@@ -619,14 +634,48 @@ def other_configs(want, cache, ncpu):
             rec["leg_wall_s"] = round(time.time() - t0, 1)
             if "algorithmic_gb_per_batch" in rec and rec.get("search_kernel_ms"):
                 ach = rec["algorithmic_gb_per_batch"] / rec["search_kernel_ms"] * 1e3
+                tr, src = config_traffic(name, rec.get("setting"))
                 rec["roofline"] = dict(bound="hbm", kernel="k_search", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                       frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
+                                       frac=round(ach / HBM_PEAK_GBS, 4), traffic=tr, traffic_source=src)
+            elif name == "adverse" and isinstance(rec.get("roofline"), dict) and rec["roofline"].get("traffic") is None:
+                tr, src = config_traffic(name, None)
+                rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr, src
             out[name] = rec
             log(f"config {name}: {rec}")
         except Exception as e:  # noqa: BLE001  (a failed leg must not lose the headline number)
             out[name] = dict(baseline_config=label, error=repr(e)[-800:])
             log(f"config {name} failed: {e!r}")
     return out
+
+
+def config_traffic(name, setting):
+    """HBM bytes per launch of a configs[2..4] leg's dominant kernel from the committed PMC pass of that leg
+    (profiles/*_config_<name>_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE run of the same command), when its setting matches."""
+    prof = os.path.join(REPO, "profiles")
+    best = (None, None)
+    for fn in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        if not fn.endswith(f"_config_{name}_pmc_traffic.json"):
+            continue
+        try:
+            pj = json.load(open(os.path.join(prof, fn)))
+        except Exception:
+            continue
+        if setting is None or (pj.get("beam") == setting.get("beam") and pj.get("mult") == setting.get("mult")):
+            best = (pj.get("hbm_bytes_per_launch"), f"profiles/{fn} (kernel {pj.get('kernel')}; separate rocprofv3 --pmc FETCH_SIZE pass of this leg, not this run)")
+    return best
+
+
+def host_cpu():
+    """(logical cpus, model name) of this box"""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
 
 
 def measured_traffic(beam, mult, n, nq_per_gpu, fraction=-3):
@@ -691,7 +740,8 @@ def cpu_baseline(np, workload, n, d, nq, cache, legs, head_names, gpu_leg, per):
             if r:
                 rec.update(reference_qps=round(r["qps"], 1), reference_threads=best_t["threads"], rows_identical_dists=r["same_dists"],
                            rows_identical_ids=r["same_ids"], rows_identical_id_sets=r["same_id_sets"])
-    return dict(value=round(top[1]["qps"], 1), unit="queries/s", cores=best_t["threads"], kind=best_t["kind"],
+    host_cores, cpu_model = host_cpu()
+    return dict(value=round(top[1]["qps"], 1), unit="queries/s", cores=best_t["threads"], host_cores=host_cores, cpu_model=cpu_model, kind=best_t["kind"],
                 sample=f"the same {nq}-query batch, same graph files; best over the settings with recall@10 > 0.95 "
                        f"({', '.join(nm[2:] + ' -> ' + format(v['qps'], '.0f') + ' QPS' for nm, v in heads.items())}; beam,multiplier) at the best of "
                        f"{', '.join(str(r['threads']) + ' -> ' + format(r['qps'], '.0f') for r in tried)} threads (GPU's setting)",

@@ -293,6 +293,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_scores(GemmArgs A) {
     const int64_t p_begin = (int64_t)ch * kGemmPointChunk;
     const int64_t p_end = (p_begin + kGemmPointChunk < w) ? (p_begin + kGemmPointChunk) : w;
     __syncthreads();  // the previous tile is done with the staging area
+    // (row numbers fetched ahead are clamped to THIS tile's last position: the block behind a tile's end belongs to another
+    // workgroup -- fetching it, rows and all, was 6 % of the kernel's traffic)
+    const int64_t tlast = p_end - 1;
     if (tid < 128) rid[tid] = ix.fi_sorted[grp.a + min(p_begin + tid, wlast)];
     // A operand: row 32 wv + col, columns 16 s + 8 half + (0..7).  The query tile passes through the LDS (where
     // the points will be staged) so that the global loads are coalesced; loads are unconditional (clamped indices,
@@ -347,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_scores(GemmArgs A) {
       _Pragma("unroll") for (int x = 0; x < nx; x++) pre[p * nx + x] = *reinterpret_cast<const f32x4 *>(src + 16 * x); \
     }                                                                                                      \
     if (tid < 128) {                                                                                       \
-      pre_n = A.pnorm2[rid[tid]];                                                                          \
-      pre_rid = ix.fi_sorted[grp.a + min((C0) + 128 + tid, wlast)];                                        \
+      if (!mips) pre_n = A.pnorm2[rid[tid]];  /* (inner product: no |p|^2 -- a 4-byte gather costs a 128-byte line per point) */ \
+      pre_rid = ix.fi_sorted[grp.a + min((C0) + 128 + tid, tlast)];                                        \
     }                                                                                                      \
   }
     WANN_FETCH(p_begin)
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
       }                                                                                                    \
     }                                                                                                      \
     if ((NEWSTEP) && tid < 128) {                                                                          \
-      pre_n = A.pnorm2[rid[tid]];                                                                          \
+      if (!mips) pre_n = A.pnorm2[rid[tid]];                                                               \
       pre_rid = ix.fi_sorted[grp.a + min((C0) + 128 + tid, wlast)];                                        \
     }                                                                                                      \
   }
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide(GemmArgs A) {
       for (int sl = 0; sl < SLABS; sl++) {
         // (the barrier that ended the previous slab: nobody reads Ps / base any more)
         if (!PIPE && sl == 0 && tid < 128) {  // (rid_cur = this step's rows; pre_rid = the next step's, published at the last slab)
-          pre_n = A.pnorm2[rid_cur[tid]];
+          if (!mips) pre_n = A.pnorm2[rid_cur[tid]];
           pre_rid = ix.fi_sorted[grp.a + min(c0 + 128 + tid, wlast)];
         }
 #pragma unroll
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide4(GemmArgs A) {
   }
     float pre_n = 0.f;
     int pre_rid = 0;
-    if (tid < 128) pre_n = A.pnorm2[rid[tid]];
+    if (tid < 128 && !mips) pre_n = A.pnorm2[rid[tid]];
     WANN_REQUEST(rid, 0, 0)
     f32x16 acc[4];
     int par = 0;
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_scores_wide4(GemmArgs A) {
             if (sl == 0 && hf == 0) base_cur[tid] = (c0 + tid < p_end) ? (mips ? 0.f : pre_n) : kHuge;  // positions beyond the window never win
             if (sl == 2 && hf == 0) pre_rid = ix.fi_sorted[grp.a + min(c0 + 128 + tid, wlast)];
             if (sl == 2 && hf == 1) rid_nxt[tid] = pre_rid;
-            if (sl == 3 && hf == 0) pre_n = A.pnorm2[rid_nxt[tid]];
+            if (sl == 3 && hf == 0 && !mips) pre_n = A.pnorm2[rid_nxt[tid]];
           }
           __syncthreads();  // the unit is staged; R is free
           if (hf == 0) WANN_REQUEST(rid_cur, sl, 1)

@@ -2097,12 +2097,14 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     cutoff = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cutoff)));
 
     bool moved = false;  // the LDS beam changed in this iteration: positions and the window are stale
+    bool pass = false;   // the finished hop's candidates (key / pass / pm): appended to the pending ones further down
+    u64 key = 0, pm = 0;
     if (WANN_LIKELY(have)) {
       // ---- the hop in flight: distances (beamSearch.h:135-145); what passes joins the pending candidates
       const float dist = mid_take_distances<METRIC>(ix, a, kept, row_off, L.qv, mode, rr, sc_r, sc_nt);
-      const bool pass = kept && (dist < cutoff);
-      const u64 key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
-      const u64 pm = ballot64(pass);
+      pass = kept && (dist < cutoff);
+      key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
+      pm = ballot64(pass);
       WANN_PHASE(0);  // vectors + distances
       if (WANN_UNLIKELY(hop_exact)) {
         // (lanes of this row shared a filter slot -- the row may list a node twice, and then the multiset union keeps two copies:
@@ -2113,14 +2115,13 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
         scan_from = p0 < scan_from ? p0 : scan_from;
         set_cutoff();
         moved = true;
+        pm = 0;
       } else if (pm) {
-        const int c = popc64(pm);
-        if (WANN_UNLIKELY(D + c > 64)) {
+        if (WANN_UNLIKELY(D + popc64(pm) > 64)) {
           unite_pending();
           moved = true;
         }
-        if (pass) pend[D + popc64(pm & lanemask_lt())] = key;
-        D += c;
+        // (they count as pending from here on; their keys reach the buffer behind the next hop's requests)
         for (u64 mm = pm; mm; mm &= mm - 1) {
           const u64 kc = rdlane64(key, ctz64(mm)) | 1ull;
           pmin = kc < pmin ? kc : pmin;
@@ -2134,21 +2135,31 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
         s1probe = true;
       }
     }
+    auto append = [&]() {  // the finished hop's candidates into the pending buffer
+      if (pm) {
+        if (pass) pend[D + popc64(pm & lanemask_lt())] = key;
+        D += popc64(pm);
+      }
+    };
     // ---- The next hop visits s1 -- the first unvisited entry of the LDS beam -- unless a pending candidate sorts at or before
     //      it (an equal key is a copy of s1's entry).  Then s1 is the closest unvisited entry of the whole beam and lies within
     //      its first B entries: s1's rank is its position.
-    if (WANN_LIKELY(have && !moved && s1n >= 0 && nvis < lim && pmin > (s1k | 1ull))) {
+    const bool committed = have && !moved && s1n >= 0 && nvis < lim && pmin > (s1k | 1ull);
+    int a_nx;
+    bool kept_nx;
+    if (WANN_LIKELY(committed)) {
       if (lane == 0) mb[s1p] = s1k | 1ull;
       wum &= ~((u64)1 << (s1p - wbase));
       nvis++;
       pos_c = s1p;
       scan_from = s1p + 1;
-      a = s1a;
-      kept = filter(s1a, s1loc, s1old, s1clash);
+      a_nx = s1a;
+      kept_nx = filter(s1a, s1loc, s1old, s1clash);
       hop_exact = s1clash;
       if (prof) acc[5]++;
     } else {
       // ---- exact beam first; then the closest unvisited entry (beamSearch.h:108-117): entries before scan_from are visited
+      append();
       unite_pending();
       WANN_PHASE(2);
       if (nvis >= lim) break;
@@ -2177,33 +2188,38 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       int old;
       bool clash;
       if (cur == s1n) {
-        a = s1a;
+        a_nx = s1a;
         if (s1probe) {
           loc = s1loc;
           old = s1old;
           clash = s1clash;
         } else {
-          prepare(a, loc, clash);
+          prepare(a_nx, loc, clash);
           old = gtable[loc];
         }
       } else {
-        a = (cur == s2n) ? s2a : load_row(cur);
-        prepare(a, loc, clash);
+        a_nx = (cur == s2n) ? s2a : load_row(cur);
+        prepare(a_nx, loc, clash);
         old = gtable[loc];
       }
-      kept = filter(a, loc, old, clash);
+      kept_nx = filter(a_nx, loc, old, clash);
       hop_exact = clash;
       load_window(pos_c + 1);
       WANN_PHASE(3);  // unexpected node / stale positions: union, scan, row, probes, filter
     }
     s1probe = false;  // (this hop's stores follow whatever probes are out)
-    WANN_PHASE(1);  // filter
-    // ---- the next two expected nodes, their rows, s1's probes; then this hop's vectors -- all requests of a hop go out together
-    expect();
-    WANN_PHASE(4);  // expectations, probes
-    mid_request_rows<METRIC>(ix, a, kept, row_off, mode, rr, sc_r, sc_nt);
-    have = true;
+    WANN_PHASE(1);    // filter
+    // ---- this hop's vectors FIRST (what the next iteration waits for), then the expectations -- s1's probes (they follow this
+    //      hop's filter stores), the rows of s1 / s2 -- and, behind all requests, the finished hop's candidates into the pending
+    //      buffer: whatever is done between a hop's requests and the next hop's costs nothing while the vectors travel
+    mid_request_rows<METRIC>(ix, a_nx, kept_nx, row_off, mode, rr, sc_r, sc_nt);
     WANN_PHASE(6);  // vector requests
+    expect();
+    if (committed) append();
+    a = a_nx;
+    kept = kept_nx;
+    have = true;
+    WANN_PHASE(4);  // expectations, probes, pending buffer
   }
 #undef WANN_PHASE
   for (int o = 32; o; o >>= 1) ncmp_v += __shfl_xor(ncmp_v, o);

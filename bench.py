@@ -168,17 +168,38 @@ def spawn_ranks(n_ranks, argv):
     return proc.returncode
 
 
-def launch_check():
-    """Self-test of the launch path without a GPU (tests/test_bench_launch.py): rendezvous on gloo, one all-gather of
-    the rank numbers, rank 0 prints a JSON line."""
+def launch_check(args):
+    """Self-test of the launch path without a GPU (tests/test_bench_launch.py): rendezvous on gloo, then one STEP of the job as the
+    real run would cut it -- the workload's batch shape, weak / strong scaling, count- or cost-balanced shards -- through
+    sharded_batch_search with a stand-in search function (row i = f(global query number)), the all-gather included; every rank
+    checks every row.  Rank 0 prints a JSON line."""
     import torch
     import torch.distributed as dist
+    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search, weighted_bounds
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+    wl = WORKLOADS[args.workload]
+    gnq = (args.nq if args.nq != 10_000 else 1003) * (world if args.scaling == "weak" else 1)  # (an odd size: uneven shards)
+    q = torch.arange(gnq * 4, dtype=torch.float32).reshape(gnq, 4)
+    r = torch.zeros((gnq, 2), dtype=torch.float32)
+    bounds = None
+    if args.balance == "cost" and world > 1:
+        bounds = weighted_bounds([1.0 + (i % 7 == 0) * 50.0 for i in range(gnq)], world)
+
+    def fake(qs, rs, base):
+        m = qs.shape[0]
+        ids = (torch.arange(base, base + m, dtype=torch.int32)[:, None] * K + torch.arange(K, dtype=torch.int32)[None, :])
+        return ids, ids.to(torch.float32) * 0.5
+    ids, dists = sharded_batch_search(fake, q, r, K, bounds=bounds)
+    want = torch.arange(gnq, dtype=torch.int32)[:, None] * K + torch.arange(K, dtype=torch.int32)[None, :]
+    ok = torch.tensor([int(bool((ids == want).all()) and bool((dists == want.to(torch.float32) * 0.5).all()))])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(json.dumps({"launch_check": world, "ranks": [int(t.item()) for t in got]}), flush=True)
+        print(json.dumps({"launch_check": world, "ranks": [int(t.item()) for t in got], "workload": wl["label"], "scaling": args.scaling,
+                          "shard_cut": args.balance, "batch": gnq, "shards": [b - a for a, b in (bounds or [shard_bounds(gnq, world, x) for x in range(world)])],
+                          "rows_ok_on_every_rank": bool(ok.item())}), flush=True)
     dist.destroy_process_group()
 
 
@@ -224,7 +245,7 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.launch_check:
-        return launch_check()
+        return launch_check(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ncpu = os.cpu_count() or 1

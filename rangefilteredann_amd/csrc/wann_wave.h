@@ -1786,16 +1786,19 @@ __device__ __forceinline__ int row_regs_blocks(const IndexView &ix) {
 
 // lane h of a pair holds the 16-byte blocks 2 j + h of its row, j < nblk -- the same addresses for float32 rows under either
 // metric and for byte rows
-template <int NR>
+// NBC > 0: the block count is a compile-time constant (no branch per block, the loads go out back to back and the scoring waits
+// for them one by one); NBC = 0: `nblk` decides at run time
+template <int NR, int NBC = 0>
 __device__ __forceinline__ void row_regs_load(RowRegs<NR> &rr, const float *__restrict__ prow, int h, int nblk) {
 #pragma unroll
   for (int j = 0; j < NR; j++)
-    if (j < nblk) rr.v[j] = *reinterpret_cast<const float4 *>(prow + 8 * j + 4 * h);
+    if (NBC > 0 ? j < NBC : j < nblk) rr.v[j] = *reinterpret_cast<const float4 *>(prow + 8 * j + 4 * h);
 }
 
-template <int METRIC, int NR>
+template <int METRIC, int NR, int NBC = 0>
 __device__ __forceinline__ float row_regs_score(const RowRegs<NR> &rr, const float *qv, const IndexView &ix, int h, int nblk) {
   if (NR == 0) return 0.f;
+  if (NBC > 0) nblk = NBC;
 #if WANN_DT != 0
   int ab = 0, aa = 0, qq = 0;  // byte_pair's arithmetic (exact integer sums: any order)
 #pragma unroll
@@ -1855,31 +1858,47 @@ __device__ __forceinline__ float row_regs_score(const RowRegs<NR> &rr, const flo
 
 // Request the rows of a hop's kept neighbours (lanes flagged `take`, entry `a`): the r-th flagged lane pushes its id to lane
 // pair r (first pass: r < 32), the pair's lanes request half a row each.  r / nt: rank of this lane among the flagged, their number.
-template <int METRIC>
+template <int METRIC, int NBC = 0>
 __device__ __forceinline__ void mid_request_rows(const IndexView &ix, int a, bool take, int64_t row_off, int mode,
-                                                 typename RowRegsFor<METRIC>::type &rr, int &r, int &nt) {
+                                                 typename RowRegsFor<METRIC>::type &rr, int &r, int &nt, int &touch) {
   const int lane = lane_id();
   const u64 tm = ballot64(take);
   nt = popc64(tm);
   r = popc64(tm & lanemask_lt());
-  if (RowRegsFor<METRIC>::NR == 0 || mode == 0 || nt == 0) return;
+  if (nt == 0) return;
+  // Rows that no register waits for -- the second pass's (more than 32 kept neighbours: a search's first hops, every other hop
+  // at beams of 160), or all of them in a kernel without the registers (mode 0) -- are fetched where they are scored: a round
+  // trip of their own.  Their cache lines are requested NOW (one dword per 128-byte line, the value is never looked at), so
+  // that round trip ends in the L2; the requests retire with this hop's other requests.
+  const int first = (RowRegsFor<METRIC>::NR == 0 || mode == 0) ? 0 : 32;
+  if (first == 0 || WANN_UNLIKELY(nt > 32)) {
+    const int got = __builtin_amdgcn_ds_permute((take && r >= first) ? ((r - first) << 2) : (63 << 2), a);  // lane j: the (first + j)-th kept id
+    const int lpr = (ix.stride * 4 + 127) >> 7, total = (nt - first) * lpr;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+      const int t = t0 + lane, j = t / lpr;
+      const int idj = __builtin_amdgcn_ds_bpermute((j & 63) << 2, got);
+      if (t < total) touch |= *reinterpret_cast<const int *>(ix.points + (row_off + idj) * (int64_t)ix.stride + (t - j * lpr) * 32);
+    }
+  }
+  if (first == 0) return;
   const bool now = take && r < 32;
   const int got = __builtin_amdgcn_ds_permute(now ? (r << 3) : 4, a);
   const int ev = pair_even_value(got);
   const int id = ((lane >> 1) < nt) ? ev : 0;  // idle pairs fetch node 0: no branches
-  row_regs_load(rr, ix.points + (row_off + id) * (int64_t)ix.stride, lane & 1, mode);
+  row_regs_load<RowRegsFor<METRIC>::NR, NBC>(rr, ix.points + (row_off + id) * (int64_t)ix.stride, lane & 1, mode);
 }
 
 // ... and their distances: every flagged lane receives the distance of its entry
-template <int METRIC>
+template <int METRIC, int NBC = 0>
 __device__ __forceinline__ float mid_take_distances(const IndexView &ix, int a, bool take, int64_t row_off, const float *qv, int mode,
-                                                    const typename RowRegsFor<METRIC>::type &rr, int r, int nt) {
+                                                    const typename RowRegsFor<METRIC>::type &rr, int r, int nt, int touch) {
+  asm volatile("" ::"v"(touch));  // (the second pass's lines: real loads, retired with the first pass's vectors)
   if (nt == 0) return 0.f;
   if (RowRegsFor<METRIC>::NR == 0 || mode == 0) return wave_distances_own<METRIC, true>(ix, a, take, qv, row_off);
   const int lane = lane_id(), h = lane & 1;
   float mine = 0.f;
   {
-    const float dd = row_regs_score<METRIC>(rr, qv, ix, h, mode);
+    const float dd = row_regs_score<METRIC, RowRegsFor<METRIC>::NR, NBC>(rr, qv, ix, h, mode);
     const float back = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((r << 1) | 1) << 2, __builtin_bit_cast(int, dd)));
     if (take && r < 32) mine = back;
   }
@@ -1889,19 +1908,26 @@ __device__ __forceinline__ float mid_take_distances(const IndexView &ix, int a, 
     const int ev = pair_even_value(got);
     const int id = (32 + (lane >> 1) < nt) ? ev : 0;
     typename RowRegsFor<METRIC>::type r2;  // (registers of its own: `rr` has ONE definition per hop, or the compiler copies it around)
-    row_regs_load(r2, ix.points + (row_off + id) * (int64_t)ix.stride, h, mode);
-    const float dd = row_regs_score<METRIC>(r2, qv, ix, h, mode);
+    row_regs_load<RowRegsFor<METRIC>::NR, NBC>(r2, ix.points + (row_off + id) * (int64_t)ix.stride, h, mode);
+    const float dd = row_regs_score<METRIC, RowRegsFor<METRIC>::NR, NBC>(r2, qv, ix, h, mode);
     const float back = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((((r - 32) << 1) | 1) << 2, __builtin_bit_cast(int, dd)));
     if (now) mine = back;
   }
   return mine;
 }
 
-template <int METRIC>
+// NBC: the blocks of a row a lane holds as a compile-time constant (the caller has checked row_regs_blocks() == NBC), 0 = by
+// the index (run time)
+template <int METRIC, int NBC = 0>
 __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const PartDesc &part, const WaveLds &L, int32_t *gtable,
                                                      uint32_t tag, int B, int bits, int64_t qid, int64_t limit, int degree_limit,
                                                      int32_t *mini, uint32_t mini_mask, int &m_out, long long &nvis_out,
-                                                     long long &ncmp_out, unsigned long long *prof = nullptr) {
+                                                     long long &ncmp_out, unsigned long long *prof = nullptr, uint32_t *wbits = nullptr,
+                                                     int wwords = 0, int wshift = 0) {
+  // wbits (LDS, wwords 32-bit words, or null): one bit per 2^wshift filter slots -- "a slot of this group has been written by
+  // this search".  A neighbour whose bit is clear finds an entry of an older epoch (or none) whatever the table holds: its probe --
+  // a 4-byte read of a random 128-byte line of a table of up to 2 MiB -- is not issued.  Under load these searches are bound by
+  // such lines, and nine probes in ten of a long search find an empty slot.
   prof = WANN_PROF_PTR(prof);
   // (every wave-uniform argument into scalar registers: see wave_beam_search_big)
   tag = (uint32_t)uni((int)tag);
@@ -1910,13 +1936,16 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
   qid = uni64(qid);
   degree_limit = uni(degree_limit);
   mini_mask = (uint32_t)uni((int)mini_mask);
+  wshift = uni(wshift);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = uni(part.start);
   const int64_t row_base = uni64(part.row_base);
   const int rs = uni(ix.rs);
   u64 *const mb = L.lbeam;
-  const int mode = (WANN_AB == 2 || RowRegsFor<METRIC>::NR == 0) ? 0 : uni(row_regs_blocks<METRIC>(ix));  // (blocks of a row a lane holds; 0: rows fetched where they are scored)
+  if (wbits)
+    for (int i = lane; i < wwords; i += 64) wbits[i] = 0u;
+  const int mode = NBC > 0 ? NBC : (WANN_AB == 2 || RowRegsFor<METRIC>::NR == 0) ? 0 : uni(row_regs_blocks<METRIC>(ix));  // (blocks of a row a lane holds; 0: rows fetched where they are scored)
   const int lim = uni(limit > 0x7fffffff ? 0x7fffffff : (int)limit);
 
   // frontier = {start node 0} (beamSearch.h:80-82)
@@ -1940,7 +1969,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
   u64 wv = lane == 0 ? key0 : 1ull, wum = 1ull;
   // the hop in flight: node at position pos_c, its row `a`, the neighbours the reference scores (`kept`), their vectors requested;
   // hop_exact: two of them share a filter slot (the row may list a node twice: its candidates are united at once, multiset rule)
-  int pos_c = -1, a = -1, sc_r = 0, sc_nt = 0, scan_from = 0;
+  int pos_c = -1, a = -1, sc_r = 0, sc_nt = 0, sc_touch = 0, scan_from = 0;
   bool kept = false, have = false, hop_exact = false;
   typename RowRegsFor<METRIC>::type rr;
   // the next two expected nodes: s1 (key s1k at position s1p; row s1a; filter slots s1loc; probes s1old, valid while s1probe;
@@ -1956,6 +1985,23 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     return v;
   };
   auto is_valid = [&](int arow) -> bool { return (arow >= 0) && (lane < degree_limit) && ((int64_t)arow != qid); };
+  // what the filter holds in a neighbour's slot (-1: nothing this search has written -- never equal to a tagged id)
+  auto probe = [&](int arow, uint32_t loc) -> int {
+    bool maybe = is_valid(arow);
+    if (wbits) {
+      const uint32_t g = loc >> wshift;
+      maybe = maybe && ((wbits[g >> 5] >> (g & 31u)) & 1u);
+    }
+    int old = -1;
+    if (maybe) old = gtable[loc];
+    return old;
+  };
+  auto mark_written = [&](bool stores, uint32_t loc) {
+    if (wbits && stores) {
+      const uint32_t g = loc >> wshift;
+      __hip_atomic_fetch_or(wbits + (g >> 5), 1u << (g & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  };
   // filter slots of a row + the exact test "two valid lanes of the row share a filter slot" (see wave_beam_search_big)
   auto prepare = [&](int arow, uint32_t &loc, bool &clash) {
     loc = (uint32_t)hash64_2((u64)(uint32_t)arow) & tmask;
@@ -1986,6 +2032,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       // are bound by such traffic, not by latency: half of what a hop moves is filter lines.)
       seen = valid && (old == tagged);
       if (valid && !seen) gtable[loc] = tagged;
+      mark_written(valid && !seen, loc);
     } else {  // exact emulation: the nearest preceding lane of the same slot, else the table; the last lane of a slot class stores
       u64 eq = ballot64(valid);
       for (int b = 0; b < bits; b++) {
@@ -1999,6 +2046,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       const int prev_val = __shfl(arow, prev_lane);
       seen = valid && (lower ? (prev_val == arow) : (old == tagged));
       if (valid && higher == 0) gtable[loc] = tagged;
+      mark_written(valid && higher == 0, loc);
     }
     const bool k = valid && !seen;
     ncmp_v += k ? 1 : 0;
@@ -2059,7 +2107,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     s2n = g2;
     if (hand1 && !s1probe) {
       prepare(s1a, s1loc, s1clash);
-      s1old = gtable[s1loc];
+      s1old = probe(s1a, s1loc);
       s1probe = true;
     }
     if (g1 >= 0 && !hand1) s1a = load_row(g1);
@@ -2101,7 +2149,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     u64 key = 0, pm = 0;
     if (WANN_LIKELY(have)) {
       // ---- the hop in flight: distances (beamSearch.h:135-145); what passes joins the pending candidates
-      const float dist = mid_take_distances<METRIC>(ix, a, kept, row_off, L.qv, mode, rr, sc_r, sc_nt);
+      const float dist = mid_take_distances<METRIC, NBC>(ix, a, kept, row_off, L.qv, mode, rr, sc_r, sc_nt, sc_touch);
       pass = kept && (dist < cutoff);
       key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
       pm = ballot64(pass);
@@ -2131,7 +2179,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       // (a row that was requested behind these vectors is back with them: its probes can go out now)
       if (s1n >= 0 && !s1probe) {
         prepare(s1a, s1loc, s1clash);
-        s1old = gtable[s1loc];
+        s1old = probe(s1a, s1loc);
         s1probe = true;
       }
     }
@@ -2195,12 +2243,12 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
           clash = s1clash;
         } else {
           prepare(a_nx, loc, clash);
-          old = gtable[loc];
+          old = probe(a_nx, loc);
         }
       } else {
         a_nx = (cur == s2n) ? s2a : load_row(cur);
         prepare(a_nx, loc, clash);
-        old = gtable[loc];
+        old = probe(a_nx, loc);
       }
       kept_nx = filter(a_nx, loc, old, clash);
       hop_exact = clash;
@@ -2212,7 +2260,8 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     // ---- this hop's vectors FIRST (what the next iteration waits for), then the expectations -- s1's probes (they follow this
     //      hop's filter stores), the rows of s1 / s2 -- and, behind all requests, the finished hop's candidates into the pending
     //      buffer: whatever is done between a hop's requests and the next hop's costs nothing while the vectors travel
-    mid_request_rows<METRIC>(ix, a_nx, kept_nx, row_off, mode, rr, sc_r, sc_nt);
+    sc_touch = 0;
+    mid_request_rows<METRIC, NBC>(ix, a_nx, kept_nx, row_off, mode, rr, sc_r, sc_nt, sc_touch);
     WANN_PHASE(6);  // vector requests
     expect();
     if (committed) append();

@@ -28,7 +28,24 @@ def test_gpus_2_without_launcher_starts_two_ranks():
                          capture_output=True, text=True, timeout=300, env=_clean_env())
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    assert json.loads(line) == {"launch_check": 2, "ranks": [0, 1]}
+    rec = json.loads(line)
+    assert rec["launch_check"] == 2 and rec["ranks"] == [0, 1] and rec["rows_ok_on_every_rank"] is True and sum(rec["shards"]) == rec["batch"]
+
+
+def test_the_drivers_8_rank_launch_line_on_the_deep_workload():
+    """What the driver's first real SCALE run does -- `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8` -- as a
+    dry run on gloo: eight ranks, the deep workload's flags, strong scaling with the cost-balanced cut, one step's sharding and
+    all-gather with a stand-in search function; every rank checks every row."""
+    sys.path.insert(0, REPO)
+    import bench
+    argv = ["--gpus", "8", "--workload", "deep", "--scaling", "strong", "--balance", "cost", "--steps", "2", "--warmup", "1", "--launch-check"]
+    env = _clean_env()
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run(bench.launcher_cmd(8, argv, bench.free_port()), capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["launch_check"] == 8 and rec["ranks"] == list(range(8)) and rec["workload"] == "deep-10M-like"
+    assert rec["rows_ok_on_every_rank"] is True and len(rec["shards"]) == 8 and sum(rec["shards"]) == rec["batch"] and len(set(rec["shards"])) > 1
 
 
 def test_gpus_must_match_world_size():

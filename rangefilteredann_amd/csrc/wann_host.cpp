@@ -1,40 +1,14 @@
-// wann_host.cpp -- C ABI (include/wann.h) of the MI355X window-filtered ANN engine: device
-// residency of the index, the batch_search driver (routing -> brute scans -> doubling rounds of
-// the beam-search kernel -> final re-search -> finalize) and the introspection entry points.
+// wann_host.cpp -- host side of the MI355X window-filtered ANN engine: device residency of the index, launch geometry and
+// the batch_search driver (routing -> brute scans -> doubling rounds of the beam-search kernel -> final re-search ->
+// finalize), the dense prefilter path's launches, the GPU build of missing graphs.  The C ABI (include/wann.h) that calls
+// into this is wann_abi.cpp; the raw-graph entry points are wann_raw.cpp.
 //
 // There is no CPU search path in this library: every compute entry point needs a gfx950 device
 // and fails loudly otherwise.
-#include <hip/hip_runtime.h>
+#include "wann_host_internal.h"
 
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <dlfcn.h>
-#include <unistd.h>
-#include <memory>
-#include <condition_variable>
-#include <mutex>
-#include <stdexcept>
-#include <string>
-#include <thread>
-#include <vector>
+namespace wann_host {
 
-#include "../../include/wann.h"
-#include "wann_build.h"
-#include "wann_device.h"
-#include "wann_gemm_device.h"
-#include "wann_gpu_build.h"
-#include "wann_hip_util.h"
-#include "wann_tuning.h"
-
-#include <rccl/rccl.h>  // types only: librccl.so is opened at first use (wann_batch_search_allgather), never linked
-
-using namespace wann;
-
-namespace {
 
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) {
@@ -67,134 +41,6 @@ void convert_rows(const HostGraph &g, int rs, int32_t *out) {
   }
 }
 
-constexpr int kInts = 160;
-enum { I_GRAPH_COUNT = 0, I_BRUTE_COUNT = 1, I_BRUTE_CURSOR = 2, I_HEAVY_COUNT = 3, I_SUB_COUNT = 4, I_BIG_COUNT = 5 /* two ints */, I_BIG_CURSOR = 7, I_DYN_COUNT = 140, I_DYN_CURSOR = 141, I_DONE = 142, I_MID_COUNT = 143, I_RISK = 144, I_BIG_RESIDENT = 145, I_POLL_WAITING = 146, I_PRIO_COUNT = 147, I_SCAN_COUNT = 148, I_CURSOR0 = 8, I_NEXT0 = 72, I_FINAL0 = 104 };
-constexpr int kMaxRounds = 30;
-constexpr int kVlogCap = 24;  // QueryParams::verbose: records per task (a doubling loop from beam 1 to 2^20 is 21 searches + the final one)
-
-struct Workspace {
-  DevBuf<Task> tasks;
-  DevBuf<int32_t> list_a, list_b, list_final, list_heavy, list_heavy_ordered, list_mid, list_big, list_brute, ints, out_cnt, g_table, g_table_big, qtask_cnt, next_beam, part_cnt, part_done;
-  DevBuf<unsigned long long> part_key;
-  DevBuf<unsigned long long> out_key, g_beam;
-  // wave_beam_search_big: per-slot exact seen bitmaps and filter epochs for the ordinary / follow-up launches
-  // (g_table) and for the companion launch (g_table_big); a table and its epochs are zeroed together
-  DevBuf<uint32_t> g_seen, g_seen_big, g_seen_f;
-  DevBuf<int32_t> g_epoch, g_epoch_big, g_epoch_f, g_table_f;  // (_f: follow-up launches, whose slot layout varies)
-  int64_t g_table_layout = -1, g_table_big_layout = -1, g_table_f_layout = -1;  // (slots << 8 | bits) of the last use
-  DevBuf<long long> sub_hops, sub_cmps;
-  DevBuf<int32_t> par_done;
-  DevBuf<Counters> ctr;
-  DevBuf<float> q_stage, r_stage, dist_stage;
-  DevBuf<uint32_t> id_stage;
-  DevBuf<unsigned long long> vlog;  // QueryParams::verbose: per-task records of the doubling loop (SearchArgs::vlog)
-  DevBuf<int32_t> vlog_n;
-  DevBuf<int32_t> gat_send, gat_recv;  // wann_batch_search_allgather: this replica's [2][cap][k] planes / everybody's [world][2][cap][k]
-  int32_t big_stride = 0;
-  int32_t *h_ints = nullptr;  // pinned
-  Counters *h_ctr = nullptr;  // pinned
-  std::vector<hipEvent_t> ev;
-  hipEvent_t ev_side = nullptr;   // end of the companion (big) launch on the index's side stream
-  hipEvent_t ev_route = nullptr;  // list sizes of k_route are on the host
-  ~Workspace() {
-    if (h_ints) (void)hipHostFree(h_ints);
-    if (h_ctr) (void)hipHostFree(h_ctr);
-    for (auto e : ev) (void)hipEventDestroy(e);
-    if (ev_side) (void)hipEventDestroy(ev_side);
-    if (ev_route) (void)hipEventDestroy(ev_route);
-  }
-  void ensure(int64_t nq, int k, int maxt, int64_t sub_slots) {
-    const size_t nt = (size_t)nq * maxt + (size_t)sub_slots;
-    par_done.ensure(nt);
-    sub_hops.ensure(nt);
-    sub_cmps.ensure(nt);
-    tasks.ensure(nt);
-    qtask_cnt.ensure(nq);
-    list_a.ensure(nt);
-    list_b.ensure(nt);
-    list_final.ensure(nt);
-    list_heavy.ensure(nt);
-    list_heavy_ordered.ensure(nt);
-    list_mid.ensure(nt);
-    list_big.ensure(4 * nt);
-    next_beam.ensure(nt);
-    big_stride = (int32_t)nt;
-    list_brute.ensure(nt);
-    ints.ensure(kInts);
-    out_cnt.ensure(nt);
-    out_key.ensure(nt * k);
-    ctr.ensure(1);
-    if (!h_ints) HIP_CHECK(hipHostMalloc((void **)&h_ints, kInts * sizeof(int32_t)));
-    if (!h_ctr) HIP_CHECK(hipHostMalloc((void **)&h_ctr, sizeof(Counters)));
-    if (!ev_side) HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
-    if (!ev_route) HIP_CHECK(hipEventCreateWithFlags(&ev_route, hipEventDisableTiming));
-    while (ev.size() < 2 + 4 * kMaxRounds) {
-      hipEvent_t e;
-      HIP_CHECK(hipEventCreate(&e));
-      ev.push_back(e);
-    }
-  }
-};
-
-}  // namespace
-
-struct wann_index {
-  HostIndex H;
-  // WANN_DEVICES (in-process multi-device mode): further replicas of the device index, one per extra device listed; a replica
-  // shares the primary's host index
-  HostIndex *Hp = nullptr;
-  HostIndex &host() { return Hp ? *Hp : H; }
-  const HostIndex &host() const { return Hp ? *Hp : H; }
-  std::vector<std::unique_ptr<wann_index>> replicas;
-  int device = 0;
-  int dtype = WANN_DTYPE_F32;  // element type of the caller's points / host queries (device rows are fp32)
-  int num_cus = 256;
-  DevBuf<float> d_points, d_labels, d_fv;
-  DevBuf<uint32_t> d_decoding;
-  DevBuf<int32_t> d_graph, d_fi;
-  DevBuf<PartDesc> d_parts;
-  DevBuf<int64_t> d_wst_off, d_wst_ptr, d_level_part0, d_level_nb, d_sup_size, d_sup_shift;
-  std::vector<PartDesc> parts;
-  std::vector<int64_t> level_part0;
-  IndexView view{};
-  int64_t device_bytes = 0;
-  Workspace ws;
-  // dense prefilter path (wann_gemm_kernels.hip): |p|^2 per point, computed at first use
-  DevBuf<float> d_pnorm2;
-  DevBuf<unsigned int> d_pnorm2_max;
-  bool have_norms = false;
-  // (touched by the blocking calls and by both asynchronous lanes, outside dense_mu for every class but PrefilterIndex)
-  std::atomic<int> dense_idle{0};  // batches in a row on which the dense path found no window group (run_batch)
-  std::atomic<uint32_t> dense_batches{0};
-  DevBuf<GemmGroup> g_groups;
-  DevBuf<int32_t> g_gq, g_tile_group, g_tq_group, g_tq_local, g_slot_count, g_slot_group, g_slot_list, g_q_slot, g_q_rank, g_plan;
-  DevBuf<unsigned long long> g_slot_key, g_score_used;
-  DevBuf<float> g_scores;
-  DevBuf<unsigned long long> g_prof;
-  hipStream_t own_stream = nullptr;
-  hipStream_t side_stream = nullptr;  // companion (big) k_search launches, concurrent with the caller's stream
-  wann_counters last{};
-  // every WANN_* switch, read when the index is created (wann_tuning.h); run_batch never reads the environment
-  // (a call works on a COPY taken under tune_mu -- snapshot_tuning: with WANN_TEST_HOOKS=1 the entry points re-read the record
-  // while a lane's worker may still be inside a batch)
-  Tuning tune;
-  std::mutex tune_mu;
-  std::mutex mu;
-  std::mutex dense_mu;  // the dense prefilter path's buffers and counters belong to the index: one batch at a time uses them
-  // wann_batch_search_device_async: further LANES -- a lane is everything one batch in flight needs (workspace, streams, a
-  // worker thread); the blocking calls use the members above
-  struct Rccl;                 // librccl.so + one communicator per replica (wann_batch_search_allgather)
-  std::unique_ptr<Rccl> rccl;
-  struct AsyncLane;
-  std::vector<std::unique_ptr<AsyncLane>> lanes;
-  std::mutex lanes_mu;   // lanes, next_ticket (held briefly)
-  std::mutex gather_mu;  // wann_batch_search_allgather: RCCL set-up, the replicas' send / receive planes and the collective, one call at a time
-  std::mutex submit_mu;  // one submission at a time (held while a submitter waits for its lane to fall idle)
-  int64_t next_ticket = 0;
-  ~wann_index();
-};
-
-namespace {
 
 // the index's switches for one call (WANN_TEST_HOOKS=1: re-read from the environment first)
 Tuning snapshot_tuning(wann_index &I) {
@@ -325,7 +171,7 @@ void upload_index(wann_index &I) {
 // (entries tagged with the slot's search epoch), the epochs, and the per-slot exact seen bitmaps.  A table whose
 // slot layout changes (or that was reallocated) is zeroed together with its epochs.
 void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBuf<uint32_t> &seen, int64_t &layout, int slots,
-                           int table_bits, int64_t seen_words, hipStream_t st, bool any_slots = false) {
+                           int table_bits, int64_t seen_words, hipStream_t st, bool any_slots) {
   const size_t need = (size_t)slots << table_bits;
   // any_slots: a slot's region depends on the table size only (slot << table_bits), so launches with different slot counts
   // share one zeroed table
@@ -340,15 +186,6 @@ void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBu
     layout = want;
   }
 }
-
-struct RoundCfg {
-  LaunchCfg lc;
-  bool big_lds;      // the one-wave-per-workgroup kernel
-  int slots;
-  int pool_bytes;    // per-wave LDS pool of this launch
-  int table_bits;    // per-slot global seen-filter of 4 << table_bits bytes (0 = none needed)
-  int64_t beam_cap;  // per-slot global beam entries (0 = none needed)
-};
 
 // Launch geometry for a k_search launch whose searches run beams in [first_beam, cap].
 // big_lds: the rare follow-up launch for beams beyond the in-kernel cap -- one wave per workgroup with a
@@ -366,8 +203,8 @@ struct RoundCfg {
 constexpr int kLdsGranule = 1280, kLdsPerCu = 160 * 1024;
 inline int lds_blocks_per_cu(int per_block) { return kLdsPerCu / (((per_block + kLdsGranule - 1) / kLdsGranule) * kLdsGranule); }
 
-RoundCfg config_for(const wann_index &I, const Tuning &T, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds = false, bool force_table = false,
-                    bool legacy = false, int base_pool = kSearchPoolBytes) {
+RoundCfg config_for(const wann_index &I, const Tuning &T, int64_t first_beam, int64_t cap, int64_t work_items, bool big_lds, bool force_table, bool legacy,
+                    int base_pool) {
   RoundCfg rc{};
   const int64_t cap_bytes = ((cap + 1) & ~(int64_t)1) * 8;
   if (cap_bytes > base_pool) big_lds = true;
@@ -1173,994 +1010,5 @@ BuildSpec make_spec(int kind, int metric, int dtype, int64_t n, int64_t d, int32
   return s;
 }
 
-}  // namespace
 
-// One batch in flight beside the others: its own workspace, streams and worker thread.  The worker runs the same run_batch
-// the blocking call runs (host-side waits included) -- on ITS stream, so the kernels of two consecutive batches share the GPU:
-// while batch i's last searches finish, batch i+1 is routed and its first workgroups take the compute units that fall free.
-struct wann_index::AsyncLane {
-  Workspace ws;
-  hipStream_t stream = nullptr, side = nullptr;
-  hipEvent_t ready = nullptr;  // the caller's inputs (recorded on the caller's stream at submission)
-  wann_counters last{};
-  struct Job {
-    const float *q, *r;
-    int64_t nq, base;
-    std::string method;
-    wann_query_params qp;
-    uint32_t *ids;
-    float *dists;
-    int64_t ticket;
-    Tuning tune;  // the index's switches as they were at submission (the worker never reads the index's record)
-  };
-  std::thread th;
-  std::mutex m;
-  std::condition_variable cv;
-  bool has_job = false, busy = false, stop = false;
-  Job job{};
-  int64_t finished = -1;  // ticket of the last finished job; its outcome:
-  int rc = WANN_OK;
-  std::string err;
-  void loop(wann_index *I) {
-    for (;;) {
-      Job j;
-      {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return has_job || stop; });
-        if (stop) return;
-        j = job;
-        has_job = false;
-      }
-      int code = WANN_OK;
-      std::string msg;
-      try {
-        HIP_CHECK(hipSetDevice(I->device));
-        HIP_CHECK(hipStreamWaitEvent(stream, ready, 0));
-        run_batch(*I, ws, side, last, j.q, j.r, j.nq, j.base, j.method.c_str(), j.qp, j.ids, j.dists, stream, j.tune);
-      } catch (HipError &e) {
-        code = WANN_ERR_HIP;
-        msg = e.what();
-      } catch (std::exception &e) {
-        code = WANN_ERR_INVALID;
-        msg = e.what();
-      }
-      {
-        std::lock_guard<std::mutex> lk(m);
-        rc = code;
-        err = msg;
-        finished = j.ticket;
-        busy = false;
-      }
-      cv.notify_all();
-    }
-  }
-  ~AsyncLane() {
-    {
-      std::lock_guard<std::mutex> lk(m);
-      stop = true;
-    }
-    cv.notify_all();
-    if (th.joinable()) th.join();
-    if (stream) (void)hipStreamDestroy(stream);
-    if (side) (void)hipStreamDestroy(side);
-    if (ready) (void)hipEventDestroy(ready);
-  }
-};
-
-// RCCL, opened with dlopen at first use: a host that never gathers on the device never loads it.
-struct wann_index::Rccl {
-  void *lib = nullptr;
-  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  std::vector<ncclComm_t> comms;
-  void open(const std::vector<int> &devices) {
-    lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) throw std::runtime_error(std::string("cannot open librccl.so: ") + dlerror());
-    auto sym = [&](const char *n) {
-      void *p = dlsym(lib, n);
-      if (!p) throw std::runtime_error(std::string("librccl.so lacks ") + n);
-      return p;
-    };
-    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
-    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
-    AllGather = (decltype(AllGather))sym("ncclAllGather");
-    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
-    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
-    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-    comms.assign(devices.size(), nullptr);
-    check(CommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
-  }
-  void check(ncclResult_t r, const char *what) const {
-    if (r != ncclSuccess) throw HipError(std::string(what) + ": " + (GetErrorString ? GetErrorString(r) : "RCCL error"));
-  }
-  ~Rccl() {
-    if (CommDestroy)
-      for (ncclComm_t c : comms)
-        if (c) (void)CommDestroy(c);
-    // (the library stays loaded: its teardown at dlclose is not worth the risk at process exit)
-  }
-};
-
-wann_index::~wann_index() {
-  rccl.reset();
-  lanes.clear();  // (joins the workers before the streams and buffers they use go away)
-  if (own_stream) (void)hipStreamDestroy(own_stream);
-  if (side_stream) (void)hipStreamDestroy(side_stream);
-}
-
-extern "C" {
-
-int wann_abi_version(void) { return WANN_ABI_VERSION; }
-const char *wann_last_error(void) { return g_err.c_str(); }
-int wann_device_count(void) { return usable_devices(); }
-
-wann_index *wann_index_create(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
-                              const float *labels, int32_t cutoff, double split_factor, double shift_factor,
-                              const wann_build_params *bp, int device, int build_threads) {
-  if (dtype != WANN_DTYPE_F32 && dtype != WANN_DTYPE_U8 && dtype != WANN_DTYPE_I8) {
-    fail(WANN_ERR_INVALID, "unknown dtype");
-    return nullptr;
-  }
-  if (kind < 0 || kind > 4 || (metric != 0 && metric != 1) || !points || !labels || n <= 0 || d <= 0) {
-    fail(WANN_ERR_INVALID, "invalid argument to wann_index_create");
-    return nullptr;
-  }
-  if (n >= (int64_t)1 << 31) {
-    fail(WANN_ERR_UNSUPPORTED, "point sets of 2^31 or more rows are not supported");
-    return nullptr;
-  }
-  // uint8 / int8 point sets (euclidian_point.h:44-60, mips_point.h:44-58: int32 accumulation, cast to float) are kept as
-  // BYTE rows on the device and scored with v_dot4 into exact int32 sums: any dimension, a quarter of the vector traffic.
-  if (usable_devices() <= device || device < 0) {
-    fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
-    return nullptr;
-  }
-  std::unique_ptr<wann_index> I(new wann_index);
-  try {
-    I->device = device;
-    I->dtype = dtype;
-    I->tune = Tuning::from_env();
-    I->H.spec = make_spec(kind, metric, dtype, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
-    std::vector<HostPart *> pending;
-    build_host_index(I->H, points, labels, -1, 0, &pending);
-    // WANN_DEVICES=a,b,...: the index is replicated on every listed device and wann_batch_search (host buffers) cuts its batch
-    // into contiguous shards, one per replica.  `device` is the primary if it is listed, else the first entry is.
-    std::vector<int> extra;
-    if (const char *dv = getenv("WANN_DEVICES")) {
-      std::vector<int> list;
-      for (const char *c = dv; *c;) {
-        char *end = nullptr;
-        const long v = strtol(c, &end, 10);
-        if (end == c) break;
-        list.push_back((int)v);
-        c = (*end == ',') ? end + 1 : end;
-      }
-      for (int v : list)
-        if (v < 0 || v >= usable_devices()) throw std::runtime_error("WANN_DEVICES names device " + std::to_string(v) + ", which does not exist");
-      if (!list.empty()) {
-        size_t prim = 0;
-        for (size_t i = 0; i < list.size(); i++)
-          if (list[i] == device) {
-            prim = i;
-            break;
-          }
-        I->device = list[prim];
-        for (size_t i = 0; i < list.size(); i++)
-          if (i != prim) extra.push_back(list[i]);
-      }
-    }
-    upload_index(*I);
-    if (!pending.empty()) build_pending(*I, pending);
-    for (int dv : extra) {  // (after the build: the graphs are in the host index by now)
-      std::unique_ptr<wann_index> R(new wann_index);
-      R->Hp = &I->H;
-      R->device = dv;
-      R->dtype = dtype;
-      R->tune = I->tune;
-      upload_index(*R);
-      I->replicas.push_back(std::move(R));
-    }
-    HIP_CHECK(hipSetDevice(I->device));
-  } catch (HipError &e) {
-    fail(WANN_ERR_HIP, e.what());
-    return nullptr;
-  } catch (std::exception &e) {
-    fail(WANN_ERR_INVALID, e.what());
-    return nullptr;
-  }
-  return I.release();
-}
-
-void wann_index_destroy(wann_index *index) { delete index; }
-
-int wann_batch_search_device(wann_index *I, const void *d_queries, const float *d_ranges, int64_t nq,
-                             int64_t query_id_base, const char *method, const wann_query_params *qp,
-                             uint32_t *d_ids, float *d_dists, void *hip_stream) {
-  if (!I || !qp || nq < 0) return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_device");
-  std::lock_guard<std::mutex> lk(I->mu);
-  try {
-    // NULL = the HIP default stream: ordered after everything the caller queued on its default stream
-    // (torch's current stream unless changed), so freshly produced inputs / recycled output blocks are safe
-    hipStream_t st = (hipStream_t)hip_stream;
-    const Tuning T = snapshot_tuning(*I);  // (WANN_TEST_HOOKS=1 only: tests flip switches between batches)
-    run_batch(*I, I->ws, I->side_stream, I->last, (const float *)d_queries, d_ranges, nq, query_id_base, method, *qp, d_ids, d_dists, st, T);
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
-  }
-  return WANN_OK;
-}
-
-// Asynchronous form of the device-buffer call (wann.h): tickets are served by kAsyncLanes lanes in turn.
-constexpr int kAsyncLanes = 2;
-
-int wann_batch_search_device_async(wann_index *I, const void *d_queries, const float *d_ranges, int64_t nq, int64_t query_id_base,
-                                   const char *method, const wann_query_params *qp, uint32_t *d_ids, float *d_dists, void *after_stream,
-                                   int64_t *ticket) {
-  if (!I || !qp || nq < 0 || !ticket) return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_device_async");
-  try {
-    // One submission at a time; lanes_mu (which wann_wait takes too) is only held to look at / publish the lane table and the
-    // ticket counter, never while this call waits for its lane to fall idle.
-    std::lock_guard<std::mutex> sub(I->submit_mu);
-    HIP_CHECK(hipSetDevice(I->device));
-    const Tuning tune = snapshot_tuning(*I);
-    int64_t t;
-    wann_index::AsyncLane *Lp;
-    {
-      std::lock_guard<std::mutex> lk(I->lanes_mu);
-      if (I->lanes.empty()) {
-        // (all lanes or none: a lane table that a failed creation left half filled would be indexed out of bounds by odd tickets)
-        std::vector<std::unique_ptr<wann_index::AsyncLane>> fresh;
-        for (int l = 0; l < kAsyncLanes; l++) {
-          std::unique_ptr<wann_index::AsyncLane> L(new wann_index::AsyncLane);
-          int prio_low = 0, prio_high = 0;
-          HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-          HIP_CHECK(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
-          HIP_CHECK(hipStreamCreateWithPriority(&L->side, hipStreamNonBlocking, prio_high));
-          HIP_CHECK(hipEventCreateWithFlags(&L->ready, hipEventDisableTiming));
-          wann_index::AsyncLane *lp = L.get();
-          L->th = std::thread([lp, I] { lp->loop(I); });
-          fresh.push_back(std::move(L));
-        }
-        I->lanes.swap(fresh);
-      }
-      t = I->next_ticket;
-      Lp = I->lanes[(size_t)(t % kAsyncLanes)].get();
-    }
-    wann_index::AsyncLane &L = *Lp;
-    {
-      std::unique_lock<std::mutex> ll(L.m);
-      L.cv.wait(ll, [&] { return !L.busy; });  // (ticket t - kAsyncLanes has finished; wann_wait it BEFORE submitting this one to see its outcome)
-      HIP_CHECK(hipEventRecord(L.ready, (hipStream_t)after_stream));
-      L.job = wann_index::AsyncLane::Job{(const float *)d_queries, d_ranges, nq, query_id_base, method ? method : "", *qp, d_ids, d_dists, t, tune};
-      L.has_job = true;
-      L.busy = true;
-    }
-    {  // the ticket exists from here on (a submission that failed above took none)
-      std::lock_guard<std::mutex> lk(I->lanes_mu);
-      I->next_ticket = t + 1;
-    }
-    L.cv.notify_all();
-    *ticket = t;
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
-  }
-  return WANN_OK;
-}
-
-int wann_wait(wann_index *I, int64_t ticket, wann_counters *out) {
-  if (!I || ticket < 0) return fail(WANN_ERR_INVALID, "invalid argument to wann_wait");
-  wann_index::AsyncLane *L = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(I->lanes_mu);
-    if (I->lanes.empty() || ticket >= I->next_ticket) return fail(WANN_ERR_INVALID, "wann_wait: no such ticket");
-    L = I->lanes[(size_t)(ticket % kAsyncLanes)].get();
-  }
-  std::unique_lock<std::mutex> ll(L->m);
-  L->cv.wait(ll, [&] { return L->finished >= ticket; });
-  if (L->finished != ticket) return fail(WANN_ERR_INVALID, "wann_wait: the ticket's lane has served a later ticket since (wait for ticket t before submitting t + 2)");
-  if (out) *out = L->last;
-  if (L->rc != WANN_OK) return fail(L->rc, L->err);
-  return WANN_OK;
-}
-
-// Shard `shard` of `world` contiguous shards of an nq-query batch (the cut of wann_batch_search's multi-device mode and of
-// wann_batch_search_allgather): first row, row count, and the common plane capacity.
-int wann_gather_layout(int64_t nq, int world, int shard, int64_t *lo, int64_t *count, int64_t *cap) {
-  if (nq < 0 || world <= 0 || shard < 0 || shard >= world) return fail(WANN_ERR_INVALID, "invalid argument to wann_gather_layout");
-  const int64_t base = nq / world, rem = nq % world;
-  if (lo) *lo = shard * base + std::min<int64_t>(shard, rem);
-  if (count) *count = base + (shard < rem ? 1 : 0);
-  if (cap) *cap = base + (rem ? 1 : 0);
-  return WANN_OK;
-}
-
-// The in-process multi-device call with DEVICE-RESIDENT, gathered result rows: every replica searches its shard into its send
-// planes and ONE ncclAllGather (RCCL over xGMI, a communicator per replica, one group call) leaves all shards' planes on every
-// replica's device.
-int wann_batch_search_allgather(wann_index *I, const void *queries, const float *ranges, int64_t nq, const char *method,
-                                const wann_query_params *qp, int32_t **d_planes, int64_t *cap_out) {
-  if (!I || !qp || nq < 0 || !d_planes || !cap_out || (nq > 0 && (!queries || !ranges)))
-    return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_allgather");
-  if (qp->k <= 0 || qp->k > 1024) return fail(WANN_ERR_INVALID, "k must be in [1, 1024]");
-  const int G = 1 + (int)I->replicas.size();
-  std::vector<wann_index *> reps{I};
-  for (auto &R : I->replicas) reps.push_back(R.get());
-  std::vector<int> devs;
-  for (wann_index *T : reps) devs.push_back(T->device);
-  for (int a = 0; a < G; a++)
-    for (int b = a + 1; b < G; b++)
-      if (devs[a] == devs[b]) return fail(WANN_ERR_UNSUPPORTED, "wann_batch_search_allgather needs DISTINCT devices in WANN_DEVICES (one RCCL rank per device)");
-  // (one call at a time: the communicators are created lazily, and the planes of a replica's workspace are read by the collective
-  // after that replica's own mutex has been released)
-  std::lock_guard<std::mutex> gather_lock(I->gather_mu);
-  try {
-    if (!I->rccl) {
-      std::unique_ptr<wann_index::Rccl> r(new wann_index::Rccl);
-      r->open(devs);
-      I->rccl = std::move(r);
-    }
-    const int64_t k = qp->k, d = I->H.spec.d, esz = I->dtype == WANN_DTYPE_F32 ? 4 : 1;
-    int64_t cap = 0;
-    wann_gather_layout(nq, G, 0, nullptr, nullptr, &cap);
-    if (cap == 0) cap = 1;
-    std::vector<std::thread> threads;
-    std::vector<int> codes((size_t)G, WANN_OK);
-    std::vector<std::string> errs((size_t)G);
-    for (int g = 0; g < G; g++) {
-      wann_index *T = reps[(size_t)g];
-      int64_t lo = 0, cnt = 0;
-      wann_gather_layout(nq, G, g, &lo, &cnt, nullptr);
-      threads.emplace_back([=, &codes, &errs] {
-        try {
-          std::lock_guard<std::mutex> lk(T->mu);
-          HIP_CHECK(hipSetDevice(T->device));
-          const Tuning tune = snapshot_tuning(*T);
-          Workspace &W = T->ws;
-          hipStream_t st = T->own_stream;
-          W.gat_send.ensure((size_t)(2 * cap * k));
-          W.gat_recv.ensure((size_t)((int64_t)G * 2 * cap * k));
-          W.q_stage.ensure((size_t)std::max<int64_t>(cnt * d, 1));
-          W.r_stage.ensure((size_t)std::max<int64_t>(cnt * 2, 1));
-          std::vector<float> qf;
-          const void *qsrc = (const char *)queries + lo * d * esz;
-          if (cnt && T->dtype != WANN_DTYPE_F32) {
-            qf = bytes_to_float(T->dtype, qsrc, cnt * d);
-            qsrc = qf.data();
-          }
-          if (cnt) {
-            HIP_CHECK(hipMemcpyAsync(W.q_stage.p, qsrc, (size_t)cnt * d * 4, hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges + 2 * lo, (size_t)cnt * 8, hipMemcpyHostToDevice, st));
-          }
-          int32_t *ids_plane = W.gat_send.p, *dist_plane = W.gat_send.p + cap * k;
-          // rows beyond this shard's count: the padding of the reference's result rows (id 0 / FLT_MAX)
-          if (cnt < cap) {
-            HIP_CHECK(hipMemsetAsync(ids_plane + cnt * k, 0, (size_t)((cap - cnt) * k) * 4, st));
-            HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(dist_plane + cnt * k), 0x7f7fffff, (size_t)((cap - cnt) * k), st));
-          }
-          run_batch(*T, W, T->side_stream, T->last, W.q_stage.p, W.r_stage.p, cnt, lo, method, *qp, (uint32_t *)ids_plane, (float *)dist_plane, st, tune);
-        } catch (HipError &e) {
-          codes[(size_t)g] = WANN_ERR_HIP;
-          errs[(size_t)g] = e.what();
-        } catch (std::exception &e) {
-          codes[(size_t)g] = WANN_ERR_INVALID;
-          errs[(size_t)g] = e.what();
-        }
-      });
-    }
-    for (auto &t : threads) t.join();
-    for (int g = 0; g < G; g++)
-      if (codes[(size_t)g] != WANN_OK) return fail(codes[(size_t)g], "replica " + std::to_string(g) + ": " + errs[(size_t)g]);
-    // one all-gather of the [2][cap][k] planes, all replicas in one group call
-    wann_index::Rccl &N = *I->rccl;
-    N.check(N.GroupStart(), "ncclGroupStart");
-    {
-      // (an open group is always closed: a failing call between the two would leave the communicators unusable)
-      struct GroupGuard {
-        wann_index::Rccl &n;
-        bool open = true;
-        ~GroupGuard() {
-          if (open) (void)n.GroupEnd();
-        }
-      } guard{N};
-      for (int g = 0; g < G; g++) {
-        wann_index *T = reps[(size_t)g];
-        HIP_CHECK(hipSetDevice(T->device));
-        N.check(N.AllGather(T->ws.gat_send.p, T->ws.gat_recv.p, (size_t)(2 * cap * k), ncclInt32, N.comms[(size_t)g], T->own_stream), "ncclAllGather");
-      }
-      guard.open = false;
-      N.check(N.GroupEnd(), "ncclGroupEnd");
-    }
-    for (int g = 0; g < G; g++) {
-      wann_index *T = reps[(size_t)g];
-      HIP_CHECK(hipSetDevice(T->device));
-      HIP_CHECK(hipStreamSynchronize(T->own_stream));
-      d_planes[g] = T->ws.gat_recv.p;
-    }
-    HIP_CHECK(hipSetDevice(I->device));
-    *cap_out = cap;
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
-  }
-  return WANN_OK;
-}
-
-// Predicted work of every query of a batch (wann.h): the batch is routed on the device without speculative levels and
-// k_task_cost prices each query's tasks.  A planning call (one small launch pair and a copy), not part of the search.
-int wann_predict_costs(wann_index *I, const float *ranges, int64_t nq, const char *method, const wann_query_params *qp, float *cost) {
-  if (!I || !qp || nq < 0 || (nq > 0 && (!ranges || !cost))) return fail(WANN_ERR_INVALID, "invalid argument to wann_predict_costs");
-  if (nq == 0) return WANN_OK;
-  std::lock_guard<std::mutex> lk(I->mu);
-  try {
-    HIP_CHECK(hipSetDevice(I->device));
-    Workspace &W = I->ws;
-    const int mcode = method_code(method);
-    const bool tree = I->host().spec.kind == WANN_KIND_TREE_PREFILTER || I->host().spec.kind == WANN_KIND_TREE_VAMANA;
-    const bool single = !tree || (mcode == M_OPTIMIZED && !qp->has_min_query_to_bucket_ratio && I->host().spec.split_factor <= 4);
-    const int maxt = single ? 1 : 96;
-    const int k = (int)std::max<int64_t>(1, std::min<int64_t>(qp->k, 1024));
-    W.ensure(nq, k, maxt, 0);
-    W.r_stage.ensure((size_t)nq * 2);
-    W.dist_stage.ensure((size_t)nq);
-    const Tuning tune = snapshot_tuning(*I);
-    hipStream_t st = I->own_stream;
-    HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemsetAsync(W.ints.p, 0, kInts * sizeof(int32_t), st));
-    HIP_CHECK(hipMemsetAsync(W.ctr.p, 0, sizeof(Counters), st));
-    RouteArgs ra{};
-    ra.ix = I->view;
-    ra.ranges = W.r_stage.p;
-    ra.nq = nq;
-    ra.method = mcode;
-    ra.maxt = maxt;
-    ra.qtask_cnt = W.qtask_cnt.p;
-    ra.k = k;
-    ra.beam = (int32_t)std::min<int64_t>(std::max<int64_t>(qp->beam_width, 1), INT32_MAX);
-    ra.max_beam = (int32_t)std::min<int64_t>(qp->postfiltering_max_beam, INT32_MAX);
-    ra.has_ratio = qp->has_min_query_to_bucket_ratio;
-    ra.ratio = qp->min_query_to_bucket_ratio;
-    ra.tasks = W.tasks.p;
-    ra.graph_list = W.list_a.p;
-    ra.graph_count = W.ints.p + I_GRAPH_COUNT;
-    ra.heavy_list = W.list_heavy.p;
-    ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
-    ra.heavy_cap = W.big_stride;
-    ra.mid_list = W.list_mid.p;
-    ra.mid_count = W.ints.p + I_MID_COUNT;
-    ra.heavy_ratio = tune.heavy_ratio;
-    ra.risk_count = W.ints.p + I_RISK;
-    ra.brute_list = W.list_brute.p;
-    ra.brute_count = W.ints.p + I_BRUTE_COUNT;
-    ra.spec = 0;  // (plain tasks only: each carries its window's size)
-    ra.spec_num = tune.spec_num;
-    ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp->beam_width);
-    ra.sub_base0 = ra.sub_cap = (int32_t)(nq * maxt);
-    ra.sub_count = W.ints.p + I_SUB_COUNT;
-    ra.big_list = W.list_big.p;
-    ra.big_count = W.ints.p + I_BIG_COUNT;
-    ra.big_stride = W.big_stride;
-    ra.ctr = W.ctr.p;
-    if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
-    CostArgs ca{};
-    ca.tasks = W.tasks.p;
-    ca.qtask_cnt = W.qtask_cnt.p;
-    ca.parts = I->view.parts;
-    ca.nq = nq;
-    ca.maxt = maxt;
-    ca.k = k;
-    ca.beam = ra.beam;
-    ca.max_beam = ra.max_beam;
-    ca.mult = (int32_t)std::min<int64_t>(std::max<int64_t>(qp->final_beam_multiply, 1), INT32_MAX);
-    ca.cost = W.dist_stage.p;
-    if (launch_task_cost(ca, st)) throw HipError(std::string("k_task_cost: ") + launch_last_error());
-    HIP_CHECK(hipMemcpyAsync(cost, W.dist_stage.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
-  }
-  return WANN_OK;
-}
-
-namespace {
-// one replica's share of a host-buffer call: stage, search (queries keep their global numbers), copy back
-void search_host_one(wann_index &T, const void *queries, const float *ranges, int64_t nq, int64_t qid_base, const char *method,
-                     const wann_query_params &qp, uint32_t *ids, float *dists) {
-  std::lock_guard<std::mutex> lk(T.mu);
-  HIP_CHECK(hipSetDevice(T.device));
-  const Tuning tune = snapshot_tuning(T);  // (WANN_TEST_HOOKS=1 only: re-read)
-  Workspace &W = T.ws;
-  const int64_t d = T.host().spec.d;
-  if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
-  W.q_stage.ensure((size_t)nq * d);
-  W.r_stage.ensure((size_t)nq * 2);
-  W.id_stage.ensure((size_t)nq * qp.k);
-  W.dist_stage.ensure((size_t)nq * qp.k);
-  hipStream_t st = T.own_stream;
-  std::vector<float> qf;  // host queries arrive in the index's element type
-  if (nq && T.dtype != WANN_DTYPE_F32) {
-    qf = bytes_to_float(T.dtype, queries, nq * d);
-    queries = qf.data();
-  }
-  if (nq) {
-    HIP_CHECK(hipMemcpyAsync(W.q_stage.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(W.r_stage.p, ranges, (size_t)nq * 8, hipMemcpyHostToDevice, st));
-  }
-  run_batch(T, W, T.side_stream, T.last, W.q_stage.p, W.r_stage.p, nq, qid_base, method, qp, W.id_stage.p, W.dist_stage.p, st, tune);
-  if (nq) {
-    HIP_CHECK(hipMemcpyAsync(ids, W.id_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(dists, W.dist_stage.p, (size_t)nq * qp.k * 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-  }
-}
-}  // namespace
-
-int wann_batch_search(wann_index *I, const void *queries, const float *ranges, int64_t nq, const char *method,
-                      const wann_query_params *qp, uint32_t *ids, float *dists) {
-  if (!I || !qp || nq < 0 || (nq > 0 && (!queries || !ranges || !ids || !dists)))
-    return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search");
-  const int G = 1 + (int)I->replicas.size();
-  if (G == 1 || nq < G) {
-    try {
-      search_host_one(*I, queries, ranges, nq, 0, method, *qp, ids, dists);
-    } catch (HipError &e) {
-      return fail(WANN_ERR_HIP, e.what());
-    } catch (std::exception &e) {
-      return fail(WANN_ERR_INVALID, e.what());
-    }
-    return WANN_OK;
-  }
-  // In-process multi-device mode (WANN_DEVICES): contiguous shards that keep their global query numbers (the reference uses
-  // a query's row number as its own id, range_filter_tree.h:62-96 + beamSearch.h:128), one host thread and one stream per
-  // replica, rows land in the caller's arrays.
-  const int64_t d = I->H.spec.d, esz = I->dtype == WANN_DTYPE_F32 ? 4 : 1;
-  std::vector<std::thread> threads;
-  std::vector<int> codes((size_t)G, WANN_OK);
-  std::vector<std::string> errs((size_t)G);
-  for (int g = 0; g < G; g++) {
-    const int64_t base = nq / G, rem = nq % G;
-    const int64_t lo = g * base + std::min<int64_t>(g, rem), cnt = base + (g < rem ? 1 : 0);
-    wann_index *T = g == 0 ? I : I->replicas[(size_t)g - 1].get();
-    threads.emplace_back([=, &codes, &errs] {
-      try {
-        search_host_one(*T, (const char *)queries + lo * d * esz, ranges + 2 * lo, cnt, lo, method, *qp, ids + lo * qp->k, dists + lo * qp->k);
-      } catch (HipError &e) {
-        codes[(size_t)g] = WANN_ERR_HIP;
-        errs[(size_t)g] = e.what();
-      } catch (std::exception &e) {
-        codes[(size_t)g] = WANN_ERR_INVALID;
-        errs[(size_t)g] = e.what();
-      }
-    });
-  }
-  for (auto &t : threads) t.join();
-  (void)hipSetDevice(I->device);
-  for (int g = 0; g < G; g++)
-    if (codes[(size_t)g] != WANN_OK) return fail(codes[(size_t)g], "replica " + std::to_string(g) + ": " + errs[(size_t)g]);
-  // counters of the call: work summed over the replicas, times of the slowest one
-  wann_counters sum = I->last;
-  for (auto &R : I->replicas) {
-    const wann_counters &c = R->last;
-    sum.beam_searches += c.beam_searches;
-    sum.hops += c.hops;
-    sum.dist_cmps += c.dist_cmps;
-    sum.brute_rows += c.brute_rows;
-    sum.label_reads += c.label_reads;
-    sum.rounds = std::max(sum.rounds, c.rounds);
-    sum.spec_searches += c.spec_searches;
-    sum.spec_hops += c.spec_hops;
-    sum.spec_dist_cmps += c.spec_dist_cmps;
-    sum.gemm_queries += c.gemm_queries;
-    sum.gemm_unproven += c.gemm_unproven;
-    sum.gemm_rescued += c.gemm_rescued;
-    sum.recovered_continuations += c.recovered_continuations;
-    sum.deep_handoffs += c.deep_handoffs;
-    sum.lookaheads_used += c.lookaheads_used;
-    sum.lookaheads_issued += c.lookaheads_issued;
-    sum.big_searches += c.big_searches;
-    sum.big_hops += c.big_hops;
-    sum.packet_hops += c.packet_hops;
-    sum.own_scorings += c.own_scorings;
-    sum.prefetched_hops += c.prefetched_hops;
-    sum.poll_timeouts += c.poll_timeouts;
-    sum.device_ms = std::max(sum.device_ms, c.device_ms);
-    sum.search_kernel_ms = std::max(sum.search_kernel_ms, c.search_kernel_ms);
-  }
-  I->last = sum;
-  return WANN_OK;
-}
-
-int wann_get_counters(const wann_index *I, wann_counters *out) {
-  if (!I || !out) return fail(WANN_ERR_INVALID, "null argument");
-  *out = I->last;
-  return WANN_OK;
-}
-
-int64_t wann_num_points(const wann_index *I) { return I ? I->H.spec.n : -1; }
-int64_t wann_dim(const wann_index *I) { return I ? I->H.spec.d : -1; }
-int64_t wann_num_levels(const wann_index *I) { return I ? (int64_t)I->H.levels.size() : -1; }
-int64_t wann_level_size(const wann_index *I, int64_t level) {
-  if (!I || level < 0 || level >= (int64_t)I->H.levels.size()) return -1;
-  return (int64_t)I->H.levels[level].size();
-}
-int wann_partition_range(const wann_index *I, int64_t level, int64_t idx, int64_t *start, int64_t *end) {
-  if (!I || level < 0 || level >= (int64_t)I->H.levels.size() || idx < 0 || idx >= (int64_t)I->H.levels[level].size())
-    return fail(WANN_ERR_INVALID, "partition out of range");
-  const HostPart &P = I->H.levels[level][idx];
-  *start = P.start;
-  *end = P.start + P.n;
-  return WANN_OK;
-}
-int wann_partition_graph(const wann_index *I, int64_t level, int64_t idx, int32_t *rows, int64_t cap_rows, int64_t max_degree) {
-  if (!I || !rows || level < 0 || level >= (int64_t)I->H.levels.size() || idx < 0 || idx >= (int64_t)I->H.levels[level].size())
-    return fail(WANN_ERR_INVALID, "partition out of range");
-  const HostPart &P = I->H.levels[level][idx];
-  if (P.g.n != P.n || cap_rows < P.n) return fail(WANN_ERR_INVALID, "no graph / buffer too small");
-  if (max_degree != (int64_t)P.g.maxdeg)
-    return fail(WANN_ERR_INVALID, "max_degree " + std::to_string((long long)max_degree) + " does not match the index's R = " +
-                                      std::to_string((long long)P.g.maxdeg) + " (rows are R+1 ints wide)");
-  memcpy(rows, P.g.rows.data(), (size_t)P.n * (size_t)(P.g.maxdeg + 1) * 4);
-  return WANN_OK;
-}
-int64_t wann_max_degree(const wann_index *I) { return I ? I->H.spec.R : -1; }
-int64_t wann_device_bytes(const wann_index *I) { return I ? I->device_bytes : -1; }
-int wann_num_replicas(const wann_index *I) { return I ? 1 + (int)I->replicas.size() : -1; }
-
-int wann_build_cache_shard(int kind, int metric, int dtype, const void *points, int64_t n, int64_t d,
-                           const float *labels, int32_t cutoff, double split_factor, double shift_factor,
-                           const wann_build_params *bp, int shard, int nshards, int build_threads) {
-  if (dtype != WANN_DTYPE_F32 && dtype != WANN_DTYPE_U8 && dtype != WANN_DTYPE_I8) return fail(WANN_ERR_INVALID, "unknown dtype");
-  if (!bp || !bp->cache_path || !*bp->cache_path) return fail(WANN_ERR_INVALID, "cache_path required");
-  if (nshards <= 0 || shard < 0 || shard >= nshards) return fail(WANN_ERR_INVALID, "bad shard");
-  try {
-    HostIndex H;
-    H.spec = make_spec(kind, metric, dtype, n, d, cutoff, split_factor, shift_factor, bp, build_threads);
-    build_host_index(H, points, labels, shard, nshards);
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
-  }
-  return WANN_OK;
-}
-
-// One graph over one contiguous slice of a point set, resident on the device: the object behind wann_raw_beam_search
-// (tests, micro-benchmarks) and behind the unfiltered VamanaIndex API.
-struct RawGraph {
-  wann_index I;  // scratch object: config_for / device properties
-  DevBuf<float> d_pts;
-  DevBuf<int32_t> d_rows;
-  DevBuf<PartDesc> d_parts;
-  int64_t n = 0, d = 0, subset_n = 0;
-  int32_t maxdeg = 0;
-  // per-call buffers, kept across calls (a VamanaIndex answers batch after batch)
-  DevBuf<float> d_q, d_rd;
-  DevBuf<int32_t> d_list, d_ints, d_rid, d_rsz, g_table, g_epoch;
-  DevBuf<Task> d_tasks;
-  DevBuf<long long> d_hops, d_cmps, d_qids;
-  DevBuf<Counters> d_ctr;
-  DevBuf<unsigned long long> g_beam, d_prof;
-  DevBuf<uint32_t> g_seen;
-  int64_t layout = -1;
-  // points: (n, d) rows of `dtype` elements (float32, or uint8 / int8 bytes: stored as byte rows)
-  void load(int device, int metric, const void *points, int64_t n_, int64_t d_, const int32_t *graph_rows, int64_t maxdeg_,
-            int64_t subset_start, int64_t subset_n_, int dtype = WANN_DTYPE_F32) {
-    HIP_CHECK(hipSetDevice(device));
-    I.device = device;
-    I.tune = Tuning::from_env();
-    hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    I.num_cus = prop.multiProcessorCount;
-    n = n_;
-    d = d_;
-    subset_n = subset_n_;
-    maxdeg = (int32_t)maxdeg_;
-    const int64_t esz = dtype == WANN_DTYPE_F32 ? 4 : 1;
-    const int64_t stride = ((d * esz + 63) / 64) * 16;  // 32-bit words per row
-    std::vector<float> pts((size_t)n * stride, 0.f);
-    for (int64_t i = 0; i < n; i++) memcpy(pts.data() + i * stride, (const char *)points + i * d * esz, (size_t)(d * esz));
-    const int rs = (int)(((maxdeg_ + 15) / 16) * 16);
-    HostGraph g;
-    g.n = subset_n;
-    g.maxdeg = (int32_t)maxdeg_;
-    g.rows.assign(graph_rows, graph_rows + (size_t)subset_n * (maxdeg_ + 1));
-    std::vector<int32_t> rows((size_t)subset_n * rs);
-    convert_rows(g, rs, rows.data());
-    d_pts.upload(pts);
-    d_rows.upload(rows);
-    std::vector<PartDesc> parts{{0, (int32_t)subset_start, (int32_t)subset_n}};
-    d_parts.upload(parts);
-    I.view.points = d_pts.p;
-    I.view.graph = d_rows.p;
-    I.view.parts = d_parts.p;
-    I.view.labels = d_pts.p;  // unused in raw mode
-    I.view.n = n;
-    I.view.d = (int32_t)d;
-    I.view.stride = (int32_t)stride;
-    I.view.rs = rs;
-    I.view.maxdeg = (int32_t)maxdeg_;
-    I.view.metric = metric;
-    I.view.dtype = dtype;
-  }
-  // one beam search per query (host buffers); cut_k > 0: the k / cut step of beamSearch.h:159-167 (first-generation core)
-  void search(const float *queries, int64_t nq, const int64_t *query_ids, int64_t beam, int64_t limit, int64_t degree_limit,
-              int64_t cut_k, double cut, int32_t *out_ids, float *out_dists, int32_t *out_sizes, int64_t *out_hops, int64_t *out_dist_cmps) {
-    HIP_CHECK(hipSetDevice(I.device));
-    std::vector<float> qv(queries, queries + (size_t)nq * d);
-    d_q.upload(qv);
-    std::vector<Task> tasks((size_t)nq);
-    std::vector<int32_t> list((size_t)nq);
-    std::vector<long long> qids((size_t)nq);
-    for (int64_t i = 0; i < nq; i++) {
-      tasks[i] = Task{(int32_t)i, T_GRAPH, 0, 0, 0, 0, 0.f, 0.f};
-      list[i] = (int32_t)i;
-      qids[i] = query_ids ? query_ids[i] : i;
-    }
-    d_tasks.upload(tasks);
-    d_list.upload(list);
-    d_qids.upload(qids);
-    std::vector<int32_t> ints{(int32_t)nq, 0, 0, 0};
-    d_ints.upload(ints);
-    d_rid.ensure((size_t)nq * beam);
-    d_rd.ensure((size_t)nq * beam);
-    d_rsz.ensure(nq);
-    d_hops.ensure(nq);
-    d_cmps.ensure(nq);
-    d_ctr.ensure(1);
-    HIP_CHECK(hipMemset(d_ctr.p, 0, sizeof(Counters)));
-    const bool with_cut = cut_k > 0;
-    if (I.tune.hooks_live) I.tune = Tuning::from_env();  // (tests flip the core switches between calls on one VamanaIndex)
-    const Tuning &T = I.tune;
-    const bool wide = I.view.rs > 64;
-    const bool old_general = T.old_general || with_cut || wide, force_general = T.force_general || with_cut || wide;
-    // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
-    // (dev: WANN_LEAN_POOL under WANN_TEST_HOOKS=1 gives the raw search the leaner per-wave pool too -- three workgroups per CU)
-    const int raw_pool = (T.hooks_live && T.lean_pool > 0) ? T.lean_pool : kSearchPoolBytes;
-    RoundCfg rc = config_for(I, T, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general, raw_pool);
-    SearchArgs sa{};
-    sa.ix = I.view;
-    sa.queries = d_q.p;
-    sa.tasks = d_tasks.p;
-    sa.list = d_list.p;
-    sa.list_count = d_ints.p;
-    sa.cursor = d_ints.p + 1;
-    sa.B = (int32_t)beam;
-    sa.cap_inkernel = (int32_t)beam;
-    sa.max_beam = INT32_MAX;
-    sa.mult = 1;
-    sa.pool_bytes = rc.pool_bytes;
-    sa.force_general = force_general ? 1 : 0;
-    sa.k = 1;
-    sa.limit = limit;
-    sa.degree_limit = (int32_t)std::min<int64_t>(degree_limit, INT32_MAX);
-    sa.ctr = d_ctr.p;
-    sa.raw = 1;
-    sa.raw_ids = d_rid.p;
-    sa.raw_dists = d_rd.p;
-    sa.raw_sizes = d_rsz.p;
-    sa.raw_hops = d_hops.p;
-    sa.raw_cmps = d_cmps.p;
-    sa.raw_qids = d_qids.p;
-    sa.cut_k = (int32_t)cut_k;
-    sa.cut = cut;
-    sa.old_general = old_general ? 1 : 0;
-    sa.helper = (rc.lc.big == 1 && T.helper) ? kHelpers : 0;
-    if (rc.table_bits) {
-      const int64_t seen_words = ((subset_n + 127) / 128) * 4;
-      ensure_filter_scratch(g_table, g_epoch, g_seen, layout, rc.slots, rc.table_bits, seen_words, nullptr);
-      sa.g_table = g_table.p;
-      sa.g_table_bits = rc.table_bits;
-      sa.g_epoch = g_epoch.p;
-      sa.g_seen = g_seen.p;
-      sa.g_seen_words = seen_words;
-    }
-    if (rc.beam_cap) {
-      sa.g_beam_cap = rc.beam_cap;
-      g_beam.ensure((size_t)rc.slots * sa.g_beam_cap);
-      sa.g_beam = g_beam.p;
-    }
-    const bool prof = T.profile_phases;
-    if (prof) {
-      d_prof.ensure(16);
-      HIP_CHECK(hipMemset(d_prof.p, 0, 16 * sizeof(unsigned long long)));
-      sa.prof = d_prof.p;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool verbose = T.verbose;
-    if (verbose) {
-      HIP_CHECK(hipEventCreate(&e0));
-      HIP_CHECK(hipEventCreate(&e1));
-      HIP_CHECK(hipEventRecord(e0, nullptr));
-    }
-    if (launch_search(sa, rc.lc, nullptr)) throw HipError(std::string("k_search: ") + launch_last_error());
-    if (verbose) HIP_CHECK(hipEventRecord(e1, nullptr));
-    HIP_CHECK(hipDeviceSynchronize());
-    if (verbose) {
-      float ms = 0.f;
-      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-      fprintf(stderr, "[wann raw] beam %ld nq %ld kernel kind %d blocks %d (%d per CU by the runtime's occupancy): %.3f ms\n", (long)beam, (long)nq, rc.lc.big, rc.lc.blocks,
-              search_occupancy(sa, rc.lc), ms);
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-    }
-    if (prof) {
-      unsigned long long h[16];
-      HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof h, hipMemcpyDeviceToHost));
-      fprintf(stderr, "[wann phases] beam=%ld nq=%ld cycles: row %llu filter %llu dist %llu merge %llu next %llu (built with make PROFILE=1?)\n", (long)beam,
-              (long)nq, h[0], h[1], h[2], h[3], h[4]);
-      fprintf(stderr, "[wann phases 5..8] %llu %llu %llu %llu (second-generation core: select / row+probes / next+requests / slot test / filter / "
-                      "next packet / distances / delta insert / truncation); probe wait %llu, flush %llu\n", h[5], h[6], h[7], h[8], h[9], h[10]);
-    }
-    HIP_CHECK(hipMemcpy(out_ids, d_rid.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(out_dists, d_rd.p, (size_t)nq * beam * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(out_sizes, d_rsz.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    std::vector<long long> hh((size_t)nq), cc((size_t)nq);
-    HIP_CHECK(hipMemcpy(hh.data(), d_hops.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(cc.data(), d_cmps.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < nq; i++) {
-      if (out_hops) out_hops[i] = hh[i];
-      if (out_dist_cmps) out_dist_cmps[i] = cc[i];
-    }
-  }
-};
-
-int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d, const int32_t *graph_rows,
-                         int64_t maxdeg, int64_t subset_start, int64_t subset_n, const float *queries, int64_t nq,
-                         const int64_t *query_ids, int64_t beam, int64_t limit, int64_t degree_limit,
-                         int32_t *out_ids, float *out_dists, int32_t *out_sizes, int64_t *out_hops,
-                         int64_t *out_dist_cmps, int device) {
-  if (usable_devices() <= device || device < 0)
-    return fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
-  if (maxdeg > WANN_MAX_DEGREE) return fail(WANN_ERR_UNSUPPORTED, "max_degree > 128 is not supported");
-  try {
-    RawGraph G;
-    G.load(device, metric, points, n, d, graph_rows, maxdeg, subset_start, subset_n);
-    G.search(queries, nq, query_ids, beam, limit, degree_limit, 0, 0.0, out_ids, out_dists, out_sizes, out_hops, out_dist_cmps);
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
-  }
-  return WANN_OK;
-}
-
-// ---- unfiltered VamanaIndex (ParlayANN/python/vamana_index.cpp:42-76, ParlayANN/python/builder.cpp) ----------------
-namespace {
-// point file: uint32 n, uint32 d, then n * d elements (point_range.h:63-93)
-void read_point_file(const char *path, int dtype, std::vector<float> &out, int64_t &n, int64_t &d, std::vector<unsigned char> *raw_out = nullptr) {
-  FILE *f = fopen(path, "rb");
-  if (!f) throw std::runtime_error(std::string("cannot open point file ") + path);
-  uint32_t head[2];
-  if (fread(head, 4, 2, f) != 2) {
-    fclose(f);
-    throw std::runtime_error(std::string("point file too short: ") + path);
-  }
-  n = head[0];
-  d = head[1];
-  const size_t cnt = (size_t)n * d, esz = dtype == WANN_DTYPE_F32 ? 4 : 1;
-  std::vector<unsigned char> raw(cnt * esz);
-  const size_t got = cnt ? fread(raw.data(), esz, cnt, f) : 0;
-  fclose(f);
-  if (got != cnt) throw std::runtime_error(std::string("point file truncated: ") + path);
-  if (dtype == WANN_DTYPE_F32) {
-    out.resize(cnt);
-    memcpy(out.data(), raw.data(), cnt * 4);
-  } else
-    out = bytes_to_float(dtype, raw.data(), (int64_t)cnt);
-  if (raw_out) raw_out->swap(raw);
-}
-}  // namespace
-
-struct wann_vamana {
-  RawGraph G;
-  int dtype = WANN_DTYPE_F32;
-  std::mutex mu;
-};
-
-wann_vamana *wann_vamana_open(int metric, int dtype, const char *data_path, const char *graph_path, int device) {
-  if ((metric != 0 && metric != 1) || dtype < 0 || dtype > 2 || !data_path || !graph_path) {
-    fail(WANN_ERR_INVALID, "invalid argument to wann_vamana_open");
-    return nullptr;
-  }
-  if (usable_devices() <= device || device < 0) {
-    fail(WANN_ERR_NO_DEVICE, "no usable gfx950 device (this library has no CPU search path)");
-    return nullptr;
-  }
-  try {
-    std::unique_ptr<wann_vamana> V(new wann_vamana);
-    V->dtype = dtype;
-    std::vector<float> pts;
-    std::vector<unsigned char> raw;
-    int64_t n = 0, d = 0;
-    read_point_file(data_path, dtype, pts, n, d, &raw);
-    HostGraph g;
-    if (!graph_file_load(graph_path, g)) throw std::runtime_error(std::string("cannot read graph file ") + graph_path);
-    if (g.n != n) throw std::runtime_error("graph file and point file disagree on the number of points");
-    if (g.maxdeg > WANN_MAX_DEGREE) throw std::runtime_error("max_degree > 128 is not supported");
-    V->G.load(device, metric, raw.data(), n, d, g.rows.data(), g.maxdeg, 0, n, dtype);
-    return V.release();
-  } catch (HipError &e) {
-    fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    fail(WANN_ERR_IO, e.what());
-  }
-  return nullptr;
-}
-
-void wann_vamana_close(wann_vamana *v) { delete v; }
-int64_t wann_vamana_num_points(const wann_vamana *v) { return v ? v->G.n : -1; }
-int64_t wann_vamana_dim(const wann_vamana *v) { return v ? v->G.d : -1; }
-
-int wann_vamana_batch_search(wann_vamana *V, const void *queries, int64_t nq, int64_t knn, int64_t beam, uint32_t *ids, float *dists) {
-  if (!V || nq < 0 || knn <= 0 || beam <= 0 || (nq > 0 && (!queries || !ids || !dists)))
-    return fail(WANN_ERR_INVALID, "invalid argument to wann_vamana_batch_search");
-  if (beam < knn) return fail(WANN_ERR_INVALID, "beam_width must be at least knn (the reference reads past its beam otherwise)");
-  std::lock_guard<std::mutex> lk(V->mu);
-  try {
-    if (nq == 0) return WANN_OK;
-    std::vector<float> qf;
-    if (V->dtype != WANN_DTYPE_F32) {
-      qf = bytes_to_float(V->dtype, queries, nq * V->G.d);
-      queries = qf.data();
-    }
-    std::vector<int32_t> bid((size_t)nq * beam), bsz((size_t)nq);
-    std::vector<float> bd((size_t)nq * beam);
-    // QueryParams(knn, beam_width, 1.35, G.size(), G.max_degree()) (vamana_index.cpp:56); query i carries id i (:66)
-    V->G.search((const float *)queries, nq, nullptr, beam, V->G.n, V->G.maxdeg, knn, 1.35, bid.data(), bd.data(), bsz.data(), nullptr, nullptr);
-    for (int64_t i = 0; i < nq; i++)
-      for (int64_t j = 0; j < knn; j++) {
-        const bool have = j < bsz[(size_t)i];  // (the reference reads past a shorter beam: defined here as id 2^32-1, FLT_MAX)
-        ids[i * knn + j] = have ? (uint32_t)bid[(size_t)(i * beam + j)] : 0xFFFFFFFFu;
-        dists[i * knn + j] = have ? bd[(size_t)(i * beam + j)] : 3.402823466e+38f;
-      }
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_INVALID, e.what());
-  }
-  return WANN_OK;
-}
-
-int wann_vamana_build_file(int metric, int dtype, const char *data_path, const char *graph_out_path, int64_t max_degree, int64_t limit,
-                           double alpha, int device) {
-  if ((metric != 0 && metric != 1) || dtype < 0 || dtype > 2 || !data_path || !graph_out_path)
-    return fail(WANN_ERR_INVALID, "invalid argument to wann_vamana_build_file");
-  try {
-    std::vector<float> pts;
-    int64_t n = 0, d = 0;
-    std::vector<unsigned char> raw;  // (byte point sets are built from their bytes: exact integer distances)
-    read_point_file(data_path, dtype, pts, n, d, &raw);
-    if (n <= 0 || d <= 0) return fail(WANN_ERR_INVALID, "empty point file");
-
-    // one Vamana graph over the points in file order = the stand-alone post-filter index's graph
-    // (knn_index::build_index, vamana/index.h:123-313, BuildParams(R, L, alpha) types.h:94).  The labels only have to be
-    // distinct and increasing for the builder to keep file order: float(i) is that below 2^24 points
-    if (n > ((int64_t)1 << 24)) return fail(WANN_ERR_UNSUPPORTED, "wann_vamana_build_file: more than 2^24 points are not supported");
-    std::vector<float> labels((size_t)n);
-    for (int64_t i = 0; i < n; i++) labels[(size_t)i] = (float)i;
-    wann_build_params bp{max_degree, limit, alpha, ""};
-    wann_index *I = wann_index_create(WANN_KIND_POSTFILTER, metric, dtype, dtype == WANN_DTYPE_F32 ? (const void *)pts.data() : (const void *)raw.data(), n, d,
-                                      labels.data(), 1000, 2, 0.5, &bp, device, 0);
-    if (!I) return WANN_ERR_HIP;  // (message already set)
-    const HostGraph &g = I->H.levels[0][0].g;
-    const bool ok = g.n == n && graph_file_save(graph_out_path, g);
-    wann_index_destroy(I);
-    if (!ok) return fail(WANN_ERR_IO, std::string("cannot write graph file ") + graph_out_path);
-  } catch (HipError &e) {
-    return fail(WANN_ERR_HIP, e.what());
-  } catch (std::exception &e) {
-    return fail(WANN_ERR_IO, e.what());
-  }
-  return WANN_OK;
-}
-
-}  // extern "C"
+}  // namespace wann_host

@@ -1720,30 +1720,37 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
 // --------------------------------------------------------------------------------------------
 // Third-generation general core: beams that do not fit the register-resident variant, in the FOUR-wave kernel
 // (129 .. its cap; round 5).  The search of wave_beam_search<.., false, true, false> -- sorted beam in the LDS, lossy
-// seen-filter in global memory, same union -- with its three dependent memory round trips per hop (adjacency row ->
-// filter probes -> vectors) taken out of the chain of hops WITHOUT helper waves: the wave itself keeps them in flight
-// across hops.
+// seen-filter in global memory, std::set_union semantics -- restructured around what the counters showed: a hop of that core
+// was ~800 instructions and ~25 DEPENDENT LDS round trips (the union's search / duplicate test / shift, the slot-sharing
+// test, compaction) beside its three dependent memory round trips (adjacency row -> filter probes -> vectors), and under
+// load it was bound by filter lines (a 128-byte line per probe and per store of a table of up to 2 MiB per search).
 //
-//  * Which node the next hops visit is nearly always known: the first unvisited beam entries behind the current one
-//    (measured on the oracle: 89 % of the hops at beam 160, 94 % at 320, 97 % at 640, 98.5 % at 1 280).  The rows of the
-//    next TWO expected nodes are requested as soon as they are known (slots s1 / s2, one register each), and the filter
-//    probes of the next expected node right after the current hop's filter stores (same wave, program order: they see
-//    them).  Row, filter slots and slot-sharing test are pure functions of the node; the probes are valid exactly while
-//    no other hop's stores have followed them.
-//  * EARLY COMMIT.  Once a hop's distances are known, so is whether the expectation holds: it does unless a passing
-//    candidate sorts at or before the expected node.  If it holds, the NEXT hop's filter step (sequential semantics kept:
-//    it runs after this hop's) and its vector requests are issued BEFORE this hop's union, which then runs under the
-//    vectors' round trip.  The union's result is needed only for the next hop's cutoff, applied when its distances return.
-//    A hop of the steady state is one memory round trip (the vectors) + distance arithmetic, instead of three round trips
-//    + union.
+//  * EXPECTATIONS.  Which node the next hops visit is nearly always known: the first unvisited beam entries behind the
+//    current one (measured on the oracle: 89 % of the hops at beam 160, 94 % at 320, 97 % at 640, 98.5 % at 1 280).  The rows
+//    of the next TWO expected nodes are requested as soon as they are known (slots s1 / s2, a register each), and s1's filter
+//    probes right after the current hop's filter stores (same wave, program order: they see them).  Row, filter slots and
+//    slot-sharing test are pure functions of the node; the probes are valid exactly while no other hop's stores followed them.
+//  * THE UNION IS DEFERRED.  Candidates that pass the cutoff go to a 64-entry PENDING buffer; the LDS beam is left alone.
+//    The reference's beam is (LDS beam U pending), truncated to B.  The next hop visits s1 -- the first unvisited entry of the
+//    LDS beam -- iff no pending key sorts at or before it (one scalar compare against the smallest pending key); then s1 is
+//    the closest unvisited entry of the whole beam and its rank there is its position, i.e. below B.  Otherwise the pending
+//    candidates are united first (ONE wave_merge for all of them) and the search goes on from the exact beam; so do the end of
+//    the search and the hop limit.  Between unions the cutoff is the LDS beam's last distance: never below the reference's,
+//    so a candidate the reference would have rejected may be admitted -- it sorts behind the reference's B-th entry, is never
+//    visited (rule above) and leaves at the next truncation.  Equal pending keys come from different hops (a hop without
+//    shared filter slots lists every node once), where the reference's per-hop union keeps one copy: wave_merge<COLLAPSE>;
+//    a hop WITH shared slots is united on its own, at once, with the multiset rule.
+//  * A HOP'S REQUESTS GO OUT TOGETHER, the vectors first; expectations, probes and the pending buffer are worked on while
+//    they travel.  The steady-state hop is one memory round trip + distance arithmetic + ~350 instructions.
 //  * Vectors are requested at one point of the hop and consumed at another (RowRegs: half a row per lane, one row per
-//    lane pair and pass, ids and results through the cross-lane network as in wave_distances_own), for the row shapes
-//    with a compile-time routine; other shapes are fetched where they are scored.
-//  * Filter entries are tagged with the slot's search epoch (as in wave_beam_search_big): no table clear per search.
+//    lane pair and pass, ids and results through the cross-lane network as in wave_distances_own) where the kernel's
+//    register budget allows; rows no register waits for (a second pass; kernels built for three waves per SIMD) are
+//    TOUCHED at request time (one dword per 128-byte line) so that their round trip ends in the L2.
+//  * Filter entries are tagged with the slot's search epoch (no table clear per search), a slot that already holds the id is
+//    not stored to, and a "slot written" bitmap in the LDS suppresses the probes of slots this search has not written.
 //
-// Everything with sequential semantics -- lossy filter, cutoff, union, visit order -- happens in the reference's order;
-// a wrong expectation costs the round trips it would have cost anyway.  Results, hops and dist_cmps are those of
-// wave_beam_search (the parity tests run every core against the oracle).
+// Everything with sequential semantics -- lossy filter, visit order, union -- follows the reference; results, hops and
+// dist_cmps are those of wave_beam_search (the parity tests run every core against the oracle).
 // --------------------------------------------------------------------------------------------
 // (NR = the most blocks a lane holds: what the kernel's register budget affords -- 16 in the squared-L2 float kernel (two waves
 // per SIMD), fewer or none in the kernels built for three)

@@ -192,9 +192,43 @@ def launch_check(args):
         m = qs.shape[0]
         ids = (torch.arange(base, base + m, dtype=torch.int32)[:, None] * K + torch.arange(K, dtype=torch.int32)[None, :])
         return ids, ids.to(torch.float32) * 0.5
-    ids, dists = sharded_batch_search(fake, q, r, K, bounds=bounds)
-    want = torch.arange(gnq, dtype=torch.int32)[:, None] * K + torch.arange(K, dtype=torch.int32)[None, :]
-    ok = torch.tensor([int(bool((ids == want).all()) and bool((dists == want.to(torch.float32) * 0.5).all()))])
+    if args.balance == "levels":
+        # a stand-in ENGINE with the doubling loop's semantics (postfilter_vamana.h:161-181): query q finds its k entries from beam
+        # 5 << (q % 4) on; a row says which query and which beam produced it
+        fmax = float(torch.finfo(torch.float32).max)
+
+        def row_of(qi, b):
+            found = b >= (5 << (qi % 4))
+            ids = torch.full((K,), 0, dtype=torch.int32)
+            ds = torch.full((K,), fmax, dtype=torch.float32)
+            m = K if found else 3
+            ids[:m] = torch.arange(m, dtype=torch.int32) + qi * 100000 + b
+            ds[:m] = torch.arange(m, dtype=torch.float32) + b
+            return ids, ds, found
+
+        def engine(qi, b, mb, m):
+            ids, ds, found = torch.zeros(K, dtype=torch.int32), torch.full((K,), fmax), False
+            while not found and b < mb:
+                ids, ds, found = row_of(qi, b)
+                if not found:
+                    b *= 2
+            fb = min(b * m, mb)
+            if fb > b:
+                ids, ds, _ = row_of(qi, fb)
+            return ids, ds
+
+        def run_group(qn, b, mb, m):
+            rows_ = [engine(int(x), b, mb, m) for x in qn.tolist()]
+            return torch.stack([a for a, _ in rows_]), torch.stack([d_ for _, d_ in rows_])
+        from rangefilteredann_amd.distributed import level_dealt_batch_search
+        levels = [1 + (i * 7) % 5 for i in range(gnq)]
+        ids, dists = level_dealt_batch_search(run_group, gnq, K, 5, 10000, 2, levels)
+        want_rows = [engine(i, 5, 10000, 2) for i in range(gnq)]
+        ok = torch.tensor([int(all(bool((ids[i] == a).all()) and bool((dists[i] == d_).all()) for i, (a, d_) in enumerate(want_rows)))])
+    else:
+        ids, dists = sharded_batch_search(fake, q, r, K, bounds=bounds)
+        want = torch.arange(gnq, dtype=torch.int32)[:, None] * K + torch.arange(K, dtype=torch.int32)[None, :]
+        ok = torch.tensor([int(bool((ids == want).all()) and bool((dists == want.to(torch.float32) * 0.5).all()))])
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(json.dumps({"launch_check": world, "ranks": [int(t.item()) for t in got], "workload": wl["label"], "scaling": args.scaling,
@@ -219,9 +253,10 @@ def main():
     ap.add_argument("--fractions", default=None, help="'all' = also sweep 2^-16..2^0 (N=1; default for sift), 'headline' = skip, or a list of exponents '-9,-6'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setting", default="", help="'beam,mult': skip the sweep and time this setting (profiling runs)")
-    ap.add_argument("--balance", choices=("count", "cost"), default="count",
-                    help="shard cut of a step's batch: equal query counts, or equal predicted work (wann_predict_costs + weighted_bounds; "
-                         "what --scaling strong wants: the step takes as long as its slowest shard)")
+    ap.add_argument("--balance", choices=("count", "cost", "levels"), default="count",
+                    help="shard cut of a step's batch: equal query counts; equal predicted work (wann_predict_costs + weighted_bounds; what "
+                         "--scaling strong wants: the step takes as long as its slowest shard); or `levels`: no query shards at all -- the "
+                         "single doubling levels of every chain are dealt to the ranks (level_dealt_batch_search, wann_batch_search_device_ids)")
     ap.add_argument("--pipeline", type=int, default=2, help="N = 1: also time the rotating batches through the ASYNCHRONOUS call, this many in flight "
                     "(wann_batch_search_device_async; reported as config.pipelined_*, never as `value`); 0 / 1 = skip")
     ap.add_argument("--rotate", type=int, default=4, help="distinct query / window draws the timed steps rotate through (1 = the same batch every step)")
@@ -258,7 +293,7 @@ def main():
     import torch.distributed as dist
     import rangefilteredann_amd  # noqa: F401  (fails loudly when the HIP extension is missing)
     import window_ann as wa
-    from rangefilteredann_amd.distributed import shard_bounds, sharded_batch_search, weighted_bounds
+    from rangefilteredann_amd.distributed import level_dealt_batch_search, levels_from_costs, shard_bounds, sharded_batch_search, weighted_bounds
 
     assert torch.cuda.is_available() and wa.device_count() > local_rank, "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
@@ -410,7 +445,25 @@ def main():
             agg[kk] += c[kk]
         return oi, od
 
+    rot_levels = None
+    if args.balance == "levels":  # predicted doubling levels per query (the same on every rank); any prediction gives the same rows
+        rot_levels = [levels_from_costs(index.predict_costs(w.cpu().numpy(), method, qp_run), beam) for w in rot_w]
+
+    def run_group(qn, b, mb, m, j):
+        """the queries numbered qn of rotation j's batch, each under its own global number, one post-filter chain started at beam b"""
+        qs, ws = rot_q[j][qn].contiguous(), rot_w[j][qn].contiguous()
+        ri = torch.empty((qn.shape[0], K), dtype=torch.int32, device=dev)
+        rd = torch.empty((qn.shape[0], K), dtype=torch.float32, device=dev)
+        index.batch_search_device_ids(qs.data_ptr(), ws.data_ptr(), qn.shape[0], qn.contiguous().data_ptr(), method,
+                                      wa.QueryParams(K, b, 1.35, 10_000_000, 10_000, m, mb, None, False), ri.data_ptr(), rd.data_ptr(), 0)
+        c = index.counters()
+        for kk in agg:
+            agg[kk] += c[kk]
+        return ri, rd
+
     def step(j=0):
+        if rot_levels is not None:  # strong scaling below the query: single doubling levels dealt to the ranks, two all-gathers
+            return level_dealt_batch_search(lambda qn, b, mb, m: run_group(qn, b, mb, m, j), gnq, K, beam, 10000, mult, rot_levels[j], device=dev)
         # query shards -> HIP batch_search on this rank's GPU -> ONE all-gather of the per-shard top-k over RCCL/xGMI
         return sharded_batch_search(search_fn, rot_q[j], rot_w[j], K, bounds=rot_bounds[j])
 

@@ -18,6 +18,8 @@
  *       src/postfilter_vamana.h:191-219, src/prefiltering.h:124-146
  *   wann_batch_search_device the same call with queries / ranges / outputs already resident in HBM
  *   wann_batch_search_device_async / wann_wait   that call without blocking: two batches in flight (src/range_filter_tree.h:62-96)
+ *   wann_batch_search_device_ids   that call for queries that are not a contiguous range of their batch: per-query own ids
+ *       (ParlayANN/algorithms/utils/beamSearch.h:128, src/range_filter_tree.h:71-72; src/postfilter_vamana.h:161-181 for what it is for)
  *   wann_query_params        QueryParams   ParlayANN/algorithms/utils/types.h:115-140, python_bindings.cpp:204-209
  *   wann_build_params        BuildParams   ParlayANN/algorithms/utils/types.h:77-112,  python_bindings.cpp:211-213
  *
@@ -34,7 +36,7 @@
 extern "C" {
 #endif
 
-#define WANN_ABI_VERSION 4
+#define WANN_ABI_VERSION 5
 #define WANN_MAX_DEGREE 128
 
 enum { WANN_OK = 0, WANN_ERR_INVALID = 1, WANN_ERR_NO_DEVICE = 2, WANN_ERR_HIP = 3, WANN_ERR_IO = 4,
@@ -146,6 +148,15 @@ int wann_batch_search_device(wann_index *index, const void *d_queries, const flo
                              int64_t nq, int64_t query_id_base, const char *method,
                              const wann_query_params *qp, uint32_t *d_ids, float *d_dists,
                              void *hip_stream);
+
+/* wann_batch_search_device for queries that do NOT form a contiguous range of their batch (ABI 5): `d_query_ids[i]` (device array of
+ * nq int64) is the global row number of queries[i] -- its "own id" (beamSearch.h:128 + range_filter_tree.h:71-72: the reference never
+ * scores the neighbour whose number equals the query's row number).  What a scheduler needs that deals single doubling LEVELS of a
+ * query's chain to different GPUs (rangefilteredann_amd/distributed.py level_dealt_batch_search; postfilter_vamana.h:161-172: every
+ * level restarts from scratch).  Otherwise as wann_batch_search_device. */
+int wann_batch_search_device_ids(wann_index *index, const void *d_queries, const float *d_ranges, int64_t nq,
+                                 const int64_t *d_query_ids, const char *method, const wann_query_params *qp,
+                                 uint32_t *d_ids, float *d_dists, void *hip_stream);
 
 /* Asynchronous form of wann_batch_search_device (ABI 4).  The reference's call is blocking (src/range_filter_tree.h:62-96: it
  * returns when every query is answered) and so are the two calls above; a serving loop that answers batch after batch leaves

@@ -2,7 +2,7 @@
 
 The package holds only what the one accelerated path needs:
 
-  csrc/            HIP kernels (wann_kernels.hip), host driver + C ABI (wann_host.cpp, include/wann.h),
+  csrc/            HIP kernels (wann_kernels.hip), host driver (wann_host.cpp) + C ABI (wann_abi.cpp, wann_raw.cpp, include/wann.h),
                    host index builder (wann_build.cpp) and the pybind11 shim (window_ann_pybind.cpp)
   libwann.so       built C-ABI library            (make -C rangefilteredann_amd/csrc)
   _window_ann*.so  built pybind11 module that mirrors the reference's `window_ann` surface

@@ -227,6 +227,21 @@ int wann_batch_search_device(wann_index *I, const void *d_queries, const float *
   return WANN_OK;
 }
 
+int wann_batch_search_device_ids(wann_index *I, const void *d_queries, const float *d_ranges, int64_t nq, const int64_t *d_query_ids,
+                                 const char *method, const wann_query_params *qp, uint32_t *d_ids, float *d_dists, void *hip_stream) {
+  if (!I || !qp || nq < 0 || (nq > 0 && !d_query_ids)) return fail(WANN_ERR_INVALID, "invalid argument to wann_batch_search_device_ids");
+  std::lock_guard<std::mutex> lk(I->mu);
+  try {
+    const Tuning T = snapshot_tuning(*I);
+    run_batch(*I, I->ws, I->side_stream, I->last, (const float *)d_queries, d_ranges, nq, 0, method, *qp, d_ids, d_dists, (hipStream_t)hip_stream, T, d_query_ids);
+  } catch (HipError &e) {
+    return fail(WANN_ERR_HIP, e.what());
+  } catch (std::exception &e) {
+    return fail(WANN_ERR_INVALID, e.what());
+  }
+  return WANN_OK;
+}
+
 // Asynchronous form of the device-buffer call (wann.h): tickets are served by kAsyncLanes lanes in turn.
 constexpr int kAsyncLanes = 2;
 

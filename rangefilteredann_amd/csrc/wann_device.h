@@ -171,7 +171,7 @@ struct SearchArgs {
   float *raw_dists;
   int32_t *raw_sizes;
   long long *raw_hops, *raw_cmps;
-  const long long *raw_qids;  // raw mode: Point::id() of each query
+  const long long *raw_qids;  // the "own id" of each query (raw mode: Point::id(); wann_batch_search_device_ids); null: qid_base + row
   unsigned long long *prof;   // dev tool: 5 per-phase cycle counters (or null)
   long long *trace;           // dev tool: trace[0] = records, then {task, beam, start, end} per search in 100 MHz ticks (or null)
   int32_t force_general;      // dev / test: never take the small-beam register path

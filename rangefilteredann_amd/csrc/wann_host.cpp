@@ -356,7 +356,8 @@ void dense_prefilter(wann_index &I, const Tuning &T, Workspace &W, const float *
 
 // W / side / last: the lane of this batch (the index's own members for the blocking calls, an AsyncLane's for the asynchronous one)
 void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &last, const float *d_queries, const float *d_ranges, int64_t nq,
-               int64_t qid_base, const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st, const Tuning &T) {
+               int64_t qid_base, const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st, const Tuning &T,
+               const int64_t *d_qids) {
   if (qp.k <= 0 || qp.k > 1024) throw std::runtime_error("k must be in [1, 1024]");
   // the brute-force classes ignore the beam (the reference driver passes beam_size = 0 there, run_our_method.py:256)
   if (qp.beam_width <= 0 && I.host().vamana_leaves) throw std::runtime_error("beam_width must be positive");
@@ -511,6 +512,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     sa.ix = I.view;
     sa.queries = d_queries;
     sa.qid_base = qid_base;
+    sa.raw_qids = reinterpret_cast<const long long *>(d_qids);  // (null unless the caller names every query's own id)
     sa.tasks = W.tasks.p;
     sa.k = k;
     sa.limit = qp.limit;

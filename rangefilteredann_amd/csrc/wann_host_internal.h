@@ -191,7 +191,8 @@ int lean_pool_bytes(const wann_index &I, const Tuning &T);
 int method_code(const char *m);
 // W / side / last: the lane of this batch (the index's own members for the blocking calls, an AsyncLane's for the asynchronous one)
 void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &last, const float *d_queries, const float *d_ranges, int64_t nq,
-               int64_t qid_base, const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st, const Tuning &T);
+               int64_t qid_base, const char *method, const wann_query_params &qp, uint32_t *d_ids, float *d_dists, hipStream_t st, const Tuning &T,
+               const int64_t *d_qids = nullptr);
 void build_pending(wann_index &I, std::vector<HostPart *> &pending);
 std::vector<float> bytes_to_float(int dtype, const void *src, int64_t count);
 BuildSpec make_spec(int kind, int metric, int dtype, int64_t n, int64_t d, int32_t cutoff, double split_factor, double shift_factor,

@@ -134,6 +134,18 @@ class Index {
     if (rc) raise_last("batch_search_device failed");
   }
 
+  // ... for queries that are not a contiguous range of their batch: query_ids_ptr = device array of their global row numbers (int64)
+  void search_device_ids(uint64_t q_ptr, uint64_t r_ptr, int64_t nq, uint64_t qids_ptr, const std::string &method, const QueryParams &qp,
+                         uint64_t ids_ptr, uint64_t dists_ptr, uint64_t stream) {
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = wann_batch_search_device_ids(h_, (const void *)q_ptr, (const float *)r_ptr, nq, (const int64_t *)qids_ptr, method.c_str(), &qp.c,
+                                        (uint32_t *)ids_ptr, (float *)dists_ptr, (void *)stream);
+    }
+    if (rc) raise_last("batch_search_device_ids failed");
+  }
+
   // asynchronous device-resident call: returns a ticket at once; wait(ticket) blocks until that batch's rows are in place
   int64_t search_device_async(uint64_t q_ptr, uint64_t r_ptr, int64_t nq, int64_t query_id_base, const std::string &method,
                               const QueryParams &qp, uint64_t ids_ptr, uint64_t dists_ptr, uint64_t after_stream) {
@@ -241,6 +253,8 @@ template <typename C>
 static void common_defs(py::class_<C> &c) {
   c.def("batch_search_device", &C::search_device, "queries_ptr"_a, "filters_ptr"_a, "num_queries"_a,
         "query_id_base"_a, "query_method"_a, "query_params"_a, "ids_ptr"_a, "dists_ptr"_a, "stream"_a = 0)
+      .def("batch_search_device_ids", &C::search_device_ids, "queries_ptr"_a, "filters_ptr"_a, "num_queries"_a, "query_ids_ptr"_a, "query_method"_a,
+           "query_params"_a, "ids_ptr"_a, "dists_ptr"_a, "stream"_a = 0)
       .def("batch_search_device_async", &C::search_device_async, "queries_ptr"_a, "filters_ptr"_a, "num_queries"_a, "query_id_base"_a,
            "query_method"_a, "query_params"_a, "ids_ptr"_a, "dists_ptr"_a, "after_stream"_a = 0)
       .def("wait", &C::wait, "ticket"_a)

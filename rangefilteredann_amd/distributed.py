@@ -136,3 +136,122 @@ def _takes_outputs(fn) -> bool:
     except (TypeError, ValueError):
         return False
     return "out_ids" in params and "out_dists" in params
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Strong scaling: the doubling LEVELS of a query's chain dealt to different ranks
+# ---------------------------------------------------------------------------------------------------------------------------
+FLT_MAX = float(torch.finfo(torch.float32).max)
+
+
+def levels_from_costs(costs: Sequence[float], beam: int, cap: int = 8) -> List[int]:
+    """Doubling levels to search ahead per query from wann_predict_costs' figures (a chain that stops at level L has cost about
+    beam * (2^L - 1)): a heuristic -- it decides who searches what, never a result row."""
+    import math
+    return [max(1, min(cap, int(math.floor(math.log2(max(float(c), float(beam)) / float(beam) + 1.0) + 1e-9)))) for c in costs]
+
+
+def _deal_and_gather(items, run_group, world: int, rank: int, k: int, dev, group):
+    """items: list of (query, beam, max_beam, mult), the SAME list on every rank.  Item i is searched by rank i % world after the
+    items are ordered longest search first (every rank gets a fair share of every length class); run_group(query_numbers, beam, max_beam,
+    mult) -> (ids, dists) serves the items of one setting.  ONE all-gather returns every item's row to every rank."""
+    order = sorted(range(len(items)), key=lambda i: (-items[i][1], items[i][2], items[i][3], items[i][0]))
+    mine = [i for pos, i in enumerate(order) if pos % world == rank]
+    cap = (len(items) + world - 1) // world
+    send = torch.zeros((2, max(cap, 1), k), dtype=torch.int32, device=dev)
+    by_setting = {}
+    for slot, i in enumerate(mine):
+        by_setting.setdefault(items[i][1:], []).append((slot, items[i][0]))
+    for (beam, max_beam, mult), lst in sorted(by_setting.items(), reverse=True):
+        qn = torch.tensor([q for _, q in lst], dtype=torch.int64, device=dev)
+        ids, dists = run_group(qn, int(beam), int(max_beam), int(mult))[:2]
+        slots = torch.tensor([s for s, _ in lst], dtype=torch.int64, device=dev)
+        send[0, slots] = ids.view(torch.int32)
+        send[1, slots] = dists.view(torch.int32)
+    if world == 1:
+        recv = send.unsqueeze(0)
+    else:
+        recv = torch.empty((world, 2, max(cap, 1), k), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(recv.view(-1, k), send.view(-1, k), group=group)
+    rows = {}
+    for pos, i in enumerate(order):
+        r, slot = pos % world, pos // world
+        rows[i] = (recv[r, 0, slot], recv[r, 1, slot].view(torch.float32))
+    return rows
+
+
+def level_dealt_batch_search(run_group: Callable, nq: int, k: int, beam: int, max_beam: int, mult: int, levels: Sequence[int], device=None,
+                             group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The batch of `sharded_batch_search`, cut for STRONG scaling: what a rank takes is not a range of queries but single searches.
+
+    The reference's doubling loop (src/postfilter_vamana.h:161-181) searches a query's partition at beam, 2 beam, 4 beam ... -- every
+    level from scratch -- until a level's final beam holds k in-window entries, then optionally once more at min(beam * multiply,
+    max_beam).  A query's levels are as independent as queries are, so the first `levels[q]` of them (a prediction: any values >= 1
+    give the same rows) are searched AHEAD as items of their own, dealt to the ranks longest first; the sequential rule -- the first
+    level with k entries decides -- is applied after ONE all-gather, and what it asks for then (the final re-search; a chain none of
+    whose predicted levels found k entries carrying on) is a second, short phase.  A rank's time is no longer its longest chain.
+
+    run_group(query_numbers (int64 tensor), beam, max_beam, multiply) -> (ids (m, k) int32, dists (m, k) float32): the engine's
+    batch_search over THOSE queries of the batch -- each under its own global number (`wann_batch_search_device_ids`; the reference's
+    "a query's own id is its row number" quirk, beamSearch.h:128) -- with QueryParams(k, beam, ..., multiply, max_beam).  A single
+    level is run_group(q, b, b + 1, 1): with max_beam = b + 1 the loop searches once at b and neither doubles nor re-searches.
+    Query classes whose batch_search is ONE post-filter chain per query (optimized_postfilter on a tree, the super tree, the
+    stand-alone post filter) -- tiny windows that take the exact scan return the same rows at every level and settle at the first."""
+    grouped = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if grouped else 1
+    rank = dist.get_rank(group) if grouped else 0
+    if len(levels) != nq:
+        raise ValueError("one level count per query")
+    beam, max_beam, mult = int(beam), int(max_beam), int(mult)
+
+    def searched_levels(q):  # levels of query q that the loop can reach at all: beam << r < max_beam
+        n = 0
+        while n < int(levels[q]) and (beam << n) < max_beam:
+            n += 1
+        return n
+    # ---- phase A: whole chains of the queries with one predicted level, single levels of the others
+    items, where = [], {}
+    for q in range(nq):
+        L = searched_levels(q)
+        if L <= 1:
+            where[(q, -1)] = len(items)
+            items.append((q, beam, max_beam, mult))
+        else:
+            for r in range(L):
+                where[(q, r)] = len(items)
+                items.append((q, beam << r, (beam << r) + 1, 1))
+    rows = _deal_and_gather(items, run_group, world, rank, k, device, group)
+    out_ids = torch.empty((nq, k), dtype=torch.int32, device=device)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
+    # ---- the sequential rule, then phase B
+    items_b, target = [], []
+    for q in range(nq):
+        if (q, -1) in where:
+            out_ids[q], out_d[q] = rows[where[(q, -1)]]
+            continue
+        L = searched_levels(q)
+        hit = None
+        for r in range(L):
+            if int((rows[where[(q, r)]][1] < FLT_MAX).sum()) >= k:
+                hit = r
+                break
+        if hit is not None:  # :173-181: the final re-search, if its beam exceeds the level's
+            b = beam << hit
+            fb = min(b * mult, max_beam)
+            if fb > b:
+                items_b.append((q, fb, fb + 1, 1))
+                target.append(q)
+            else:
+                out_ids[q], out_d[q] = rows[where[(q, hit)]]
+        else:  # every searched level was short: the loop carries on at beam << L -- if that is still below max_beam
+            b = beam << L
+            if b < max_beam:
+                items_b.append((q, b, max_beam, mult))
+                target.append(q)
+            else:  # (the loop ends with the last level's short rows; min(b * mult, max_beam) <= b: no re-search)
+                out_ids[q], out_d[q] = rows[where[(q, L - 1)]]
+    if items_b:  # (the same list on every rank: it follows from the gathered rows)
+        rows_b = _deal_and_gather(items_b, run_group, world, rank, k, device, group)
+        for i, q in enumerate(target):
+            out_ids[q], out_d[q] = rows_b[i]
+    return out_ids, out_d

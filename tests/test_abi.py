@@ -23,7 +23,7 @@ def test_header_symbols_exported(wa):
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"libwann.so does not export {n}"
-    assert lib.wann_abi_version() == 4
+    assert lib.wann_abi_version() == 5
 
 
 def test_python_surface_matches_reference_names(wa):

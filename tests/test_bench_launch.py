@@ -48,6 +48,20 @@ def test_the_drivers_8_rank_launch_line_on_the_deep_workload():
     assert rec["rows_ok_on_every_rank"] is True and len(rec["shards"]) == 8 and sum(rec["shards"]) == rec["batch"] and len(set(rec["shards"])) > 1
 
 
+def test_levels_dealt_step_on_four_ranks():
+    """--balance levels: the step deals single doubling levels to the ranks (level_dealt_batch_search); dry run with a stand-in engine
+    that has the doubling loop's semantics"""
+    sys.path.insert(0, REPO)
+    import bench
+    argv = ["--gpus", "4", "--scaling", "strong", "--balance", "levels", "--nq", "41", "--launch-check"]
+    env = _clean_env()
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run(bench.launcher_cmd(4, argv, bench.free_port()), capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["launch_check"] == 4 and rec["shard_cut"] == "levels" and rec["rows_ok_on_every_rank"] is True
+
+
 def test_gpus_must_match_world_size():
     env = _clean_env()
     env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")

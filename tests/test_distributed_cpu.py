@@ -126,3 +126,57 @@ def test_shard_bounds_cover_everything():
             assert edges[0][0] == 0 and edges[-1][1] == nq
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in edges) <= shard_capacity(nq, world)
+
+
+def _level_worker(rank, world, port, out_dir, kind, mult, max_beam):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WANN_NO_TORCH="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from rangefilteredann_amd.distributed import level_dealt_batch_search
+    n, d, nq, k, beam = 2500, 16, 37, 10, 5
+    g = sift_like(n, d, 5)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 6)
+    rng = np.random.default_rng(9)
+    # windows from 2^-7 (exact scans on the tree) to 2^-1: chains of one to six levels
+    W = np.concatenate([windows(labels, nq, p, 50 + p)[i::6] for i, p in enumerate((-7, -5, -4, -3, -2, -1))])[:nq].astype(np.float32)
+    if kind == "tree":
+        idx = orc.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=300, split_factor=2, build_params=orc.BuildParams(16, 32, 1.0, ""), threads=2)
+        search = lambda qp: idx.batch_search(Q, W, nq, "optimized_postfilter", qp)  # noqa: E731
+    else:
+        idx = orc.PostfilterVamanaIndexFloatEuclidian(X, filters=labels, build_params=orc.BuildParams(16, 32, 1.0, ""), threads=2)
+        search = lambda qp: idx.batch_search(Q, W, nq, qp)  # noqa: E731
+    cache, calls = {}, []
+
+    def run_group(qn, b, mb, m):
+        """the oracle has no per-query ids: the WHOLE batch is searched at that setting (row numbers = ids) and the rows asked for are returned"""
+        calls.append((tuple(qn.tolist()), b, mb, m))
+        if (b, mb, m) not in cache:
+            cache[(b, mb, m)] = search(orc.QueryParams(k, b, 1.35, 10**7, 10**4, m, mb, None, False))
+        ids, dists = cache[(b, mb, m)]
+        sel = qn.numpy()
+        return torch.from_numpy(ids[sel].view(np.int32).copy()), torch.from_numpy(dists[sel].copy())
+
+    levels = rng.integers(1, 6, nq).tolist()  # (the same prediction on every rank; ANY values must give the same rows)
+    ids, dists = level_dealt_batch_search(run_group, nq, k, beam, max_beam, mult, levels)
+    eids, edists = search(orc.QueryParams(k, beam, 1.35, 10**7, 10**4, mult, max_beam, None, False))
+    ok = np.array_equal(ids.numpy().view(np.uint32), eids) and np.array_equal(dists.numpy(), edists)
+    # every rank searched something, and nobody searched a query's every level (the levels were dealt)
+    singles = [c for c in calls if c[2] == c[1] + 1]
+    ok = ok and len(calls) > 0 and (world == 1 or len(singles) > 0)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind,mult,max_beam", [(2, "tree", 1, 10000), (4, "tree", 3, 10000), (8, "post", 2, 10000), (2, "post", 1, 60), (4, "tree", 4, 100)])
+def test_doubling_levels_dealt_to_ranks_give_the_single_process_rows(oracle, tmp_path, world, kind, mult, max_beam):
+    """Strong scaling below the query: the doubling levels of a query's chain (src/postfilter_vamana.h:161-181: every level restarts
+    from scratch) searched as items of their own by different ranks, the sequential rule applied after the all-gather, final
+    re-searches (multiply > 1) and chains that outgrow their predicted levels in a second phase, loops that end at max_beam (60 /
+    100: overshoot and short results) -- rows identical to the plain call on 2 / 4 / 8 gloo ranks, the oracle as search function."""
+    mp.spawn(_level_worker, args=(world, _free_port(), str(tmp_path), kind, mult, max_beam), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"ok{r}").read() == "1"

@@ -1172,3 +1172,44 @@ def test_prefilter_classes_accept_beam_zero(oracle, wa, gpu):
         assert ok, f"{cls}: {why}"
     with pytest.raises(RuntimeError, match="beam_width must be positive"):
         wa.PostfilterVamanaIndexFloatEuclidian(X, labels, wa.BuildParams(8, 16, 1.0, "")).batch_search(Q, W, nq, _qp(wa, 0, 1, 10))
+
+
+def test_per_query_ids_and_levels_dealt_search(wa, gpu, oracle, tmp_path):
+    """wann_batch_search_device_ids (ABI 5): a non-contiguous subset of a batch, every query under its own global row number, returns
+    that subset's rows of the whole batch's call (the reference's own-id quirk, beamSearch.h:128: rows depend on the number); and
+    level_dealt_batch_search over it -- single doubling levels as items of their own, the sequential rule afterwards -- returns the
+    plain call's rows for any prediction of the level counts (postfilter_vamana.h:161-181)."""
+    import torch
+    from rangefilteredann_amd.distributed import level_dealt_batch_search
+    n, d, nq, k = 6000, 32, 120, 10
+    g = sift_like(n, d, 41)
+    X, Q = g(n), g(nq)
+    labels = distinct_labels(n, 42)
+    W = np.concatenate([windows(labels, nq, p, 70 + p)[i::5] for i, p in enumerate((-8, -6, -4, -3, -1))])[:nq].astype(np.float32)
+    idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=400, split_factor=2, build_params=wa.BuildParams(32, 64, 1.0, str(tmp_path) + "/"))
+    dev = torch.device("cuda:0")
+    Qt, Wt = torch.from_numpy(Q).to(dev), torch.from_numpy(W).to(dev)
+    # ids of the queries: some name nodes of the partitions they search (row numbers ARE small integers: the quirk is live)
+    for beam, mult, max_beam in ((5, 1, 10000), (10, 3, 10000), (5, 2, 70)):
+        qp = wa.QueryParams(k, beam, 1.35, 10**7, 10**4, mult, max_beam, None, False)
+        eids, edists = idx.batch_search(Q, W, nq, "optimized_postfilter", qp)
+        sel = torch.tensor(sorted(np.random.default_rng(beam).choice(nq, 50, replace=False).tolist()), dtype=torch.int64, device=dev)
+        oi = torch.empty((len(sel), k), dtype=torch.int32, device=dev)
+        od = torch.empty((len(sel), k), dtype=torch.float32, device=dev)
+        idx.batch_search_device_ids(Qt[sel].contiguous().data_ptr(), Wt[sel].contiguous().data_ptr(), len(sel), sel.data_ptr(), "optimized_postfilter", qp,
+                                    oi.data_ptr(), od.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(oi.cpu().numpy().view(np.uint32), eids[sel.cpu().numpy()]) and np.array_equal(od.cpu().numpy(), edists[sel.cpu().numpy()])
+
+        def run_group(qn, b, mb, m):
+            qs, ws = Qt[qn].contiguous(), Wt[qn].contiguous()
+            ri = torch.empty((len(qn), k), dtype=torch.int32, device=dev)
+            rd = torch.empty((len(qn), k), dtype=torch.float32, device=dev)
+            idx.batch_search_device_ids(qs.data_ptr(), ws.data_ptr(), len(qn), qn.contiguous().data_ptr(), "optimized_postfilter",
+                                        wa.QueryParams(k, b, 1.35, 10**7, 10**4, m, mb, None, False), ri.data_ptr(), rd.data_ptr(), 0)
+            return ri, rd
+        levels = np.random.default_rng(100 + beam).integers(1, 7, nq).tolist()
+        ids, dists = level_dealt_batch_search(run_group, nq, k, beam, max_beam, mult, levels, device=dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(dists.cpu().numpy(), edists), (beam, mult, max_beam)
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32), eids), (beam, mult, max_beam)

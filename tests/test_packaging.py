@@ -16,7 +16,7 @@ def test_pip_install_target_imports(tmp_path):
     for rel in ("window_ann/__init__.py", "rangefilteredann_amd/libwann.so", "include/wann.h"):
         assert (target / rel).exists(), rel
     code = ("import window_ann, rangefilteredann_amd as r, os; assert os.path.dirname(r.__file__).startswith(%r); "
-            "assert r.abi_version() == 4; assert hasattr(window_ann, 'VamanaRangeFilterTreeIndexFloatEuclidian'); print('ok')" % str(target))
+            "assert r.abi_version() == 5; assert hasattr(window_ann, 'VamanaRangeFilterTreeIndexFloatEuclidian'); print('ok')" % str(target))
     env = dict(os.environ, PYTHONPATH=str(target), WANN_NO_TORCH="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -1,5 +1,5 @@
 """CPU: the engine's host-side C++ (index layout + host Vamana builder in wann_build.cpp, the C ABI's host side in
-wann_host.cpp) built with g++ -fsanitize=address,undefined and run (`make -C rangefilteredann_amd/csrc sanitize`)."""
+wann_host.cpp / wann_abi.cpp / wann_raw.cpp) built with g++ -fsanitize=address,undefined and run (`make -C rangefilteredann_amd/csrc sanitize`)."""
 import os
 import subprocess
 

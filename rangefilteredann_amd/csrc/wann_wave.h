@@ -1744,8 +1744,8 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
 //    they travel.  The steady-state hop is one memory round trip + distance arithmetic + ~350 instructions.
 //  * Vectors are requested at one point of the hop and consumed at another (RowRegs: half a row per lane, one row per
 //    lane pair and pass, ids and results through the cross-lane network as in wave_distances_own) where the kernel's
-//    register budget allows; rows no register waits for (a second pass; kernels built for three waves per SIMD) are
-//    TOUCHED at request time (one dword per 128-byte line) so that their round trip ends in the L2.
+//    register budget allows (elsewhere they are fetched where they are scored); a second pass's rows are TOUCHED at request
+//    time (one dword per 128-byte line) so that their round trip ends in the L2.
 //  * Filter entries are tagged with the slot's search epoch (no table clear per search), a slot that already holds the id is
 //    not stored to, and a "slot written" bitmap in the LDS suppresses the probes of slots this search has not written.
 //
@@ -1873,21 +1873,22 @@ __device__ __forceinline__ void mid_request_rows(const IndexView &ix, int a, boo
   nt = popc64(tm);
   r = popc64(tm & lanemask_lt());
   if (nt == 0) return;
-  // Rows that no register waits for -- the second pass's (more than 32 kept neighbours: a search's first hops, every other hop
-  // at beams of 160), or all of them in a kernel without the registers (mode 0) -- are fetched where they are scored: a round
-  // trip of their own.  Their cache lines are requested NOW (one dword per 128-byte line, the value is never looked at), so
-  // that round trip ends in the L2; the requests retire with this hop's other requests.
-  const int first = (RowRegsFor<METRIC>::NR == 0 || mode == 0) ? 0 : 32;
-  if (first == 0 || WANN_UNLIKELY(nt > 32)) {
-    const int got = __builtin_amdgcn_ds_permute((take && r >= first) ? ((r - first) << 2) : (63 << 2), a);  // lane j: the (first + j)-th kept id
-    const int lpr = (ix.stride * 4 + 127) >> 7, total = (nt - first) * lpr;
+  if (RowRegsFor<METRIC>::NR == 0 || mode == 0) return;  // (rows fetched where they are scored: see below)
+  // The second pass's rows (more than 32 kept neighbours: a search's first hops, every other hop at beams of 160) are fetched
+  // when the first pass has been scored -- a round trip of their own.  Their cache lines are requested NOW (one dword per
+  // 128-byte line, the value is never looked at), so that round trip ends in the L2; the requests retire with this hop's other
+  // requests.  (The same for ALL rows of a kernel without the registers -- mode 0 -- was measured and dropped: the real loads
+  // follow the touches within ~1 500 cycles, too soon to gain from them, and under load 40 % of the touched lines were
+  // fetched twice: 6 % slower alone, 10 % under load on an inner-product graph, FETCH_SIZE of the deep-like leg 1.15 -> 1.26 x.)
+  if (WANN_UNLIKELY(nt > 32)) {
+    const int got = __builtin_amdgcn_ds_permute((take && r >= 32) ? ((r - 32) << 2) : (63 << 2), a);  // lane j: the (32 + j)-th kept id
+    const int lpr = (ix.stride * 4 + 127) >> 7, total = (nt - 32) * lpr;
     for (int t0 = 0; t0 < total; t0 += 64) {
       const int t = t0 + lane, j = t / lpr;
       const int idj = __builtin_amdgcn_ds_bpermute((j & 63) << 2, got);
       if (t < total) touch |= *reinterpret_cast<const int *>(ix.points + (row_off + idj) * (int64_t)ix.stride + (t - j * lpr) * 32);
     }
   }
-  if (first == 0) return;
   const bool now = take && r < 32;
   const int got = __builtin_amdgcn_ds_permute(now ? (r << 3) : 4, a);
   const int ev = pair_even_value(got);
@@ -1901,7 +1902,10 @@ __device__ __forceinline__ float mid_take_distances(const IndexView &ix, int a, 
                                                     const typename RowRegsFor<METRIC>::type &rr, int r, int nt, int touch) {
   asm volatile("" ::"v"(touch));  // (the second pass's lines: real loads, retired with the first pass's vectors)
   if (nt == 0) return 0.f;
-  if (RowRegsFor<METRIC>::NR == 0 || mode == 0) return wave_distances_own<METRIC, true>(ix, a, take, qv, row_off);
+  // (no registers held across the hop: the compile-time routines where the row shape has one -- a whole row per lane pair in flight,
+  // one round trip per pass)
+  // (a kernel that holds RowRegs for other row shapes has no room for a second whole row: the lean routines there)
+  if (RowRegsFor<METRIC>::NR == 0 || mode == 0) return wave_distances_own<METRIC, (RowRegsFor<METRIC>::NR != 0 || WANN_AB == 6)>(ix, a, take, qv, row_off);
   const int lane = lane_id(), h = lane & 1;
   float mine = 0.f;
   {

@@ -1196,8 +1196,8 @@ def test_per_query_ids_and_levels_dealt_search(wa, gpu, oracle, tmp_path):
         sel = torch.tensor(sorted(np.random.default_rng(beam).choice(nq, 50, replace=False).tolist()), dtype=torch.int64, device=dev)
         oi = torch.empty((len(sel), k), dtype=torch.int32, device=dev)
         od = torch.empty((len(sel), k), dtype=torch.float32, device=dev)
-        idx.batch_search_device_ids(Qt[sel].contiguous().data_ptr(), Wt[sel].contiguous().data_ptr(), len(sel), sel.data_ptr(), "optimized_postfilter", qp,
-                                    oi.data_ptr(), od.data_ptr(), 0)
+        qsel, wsel = Qt[sel].contiguous(), Wt[sel].contiguous()  # (kept alive: a temporary's block goes back to the allocator at once)
+        idx.batch_search_device_ids(qsel.data_ptr(), wsel.data_ptr(), len(sel), sel.data_ptr(), "optimized_postfilter", qp, oi.data_ptr(), od.data_ptr(), 0)
         torch.cuda.synchronize()
         assert np.array_equal(oi.cpu().numpy().view(np.uint32), eids[sel.cpu().numpy()]) and np.array_equal(od.cpu().numpy(), edists[sel.cpu().numpy()])
 

@@ -1979,7 +1979,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
   int wbase = 0;
   u64 wv = lane == 0 ? key0 : 1ull, wum = 1ull;
   // the hop in flight: node at position pos_c, its row `a`, the neighbours the reference scores (`kept`), their vectors requested;
-  // hop_exact: two of them share a filter slot (the row may list a node twice: its candidates are united at once, multiset rule)
+  // hop_exact: the row lists a node twice within a filter-slot class (its candidates may hold a key twice: united at once, multiset rule)
   int pos_c = -1, a = -1, sc_r = 0, sc_nt = 0, sc_touch = 0, scan_from = 0;
   bool kept = false, have = false, hop_exact = false;
   typename RowRegsFor<METRIC>::type rr;
@@ -2032,11 +2032,14 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     }
     clash = uni((int)c) != 0;
   };
-  // lossy seen-filter with the reference's sequential semantics (beamSearch.h:68-73,126-131): what the reference scores
-  auto filter = [&](int arow, uint32_t loc, int old, bool clash) -> bool {
+  // lossy seen-filter with the reference's sequential semantics (beamSearch.h:68-73,126-131): what the reference scores.
+  // twice: the row lists one node in two lanes of a slot class (the reference's builder can append the start point twice) -- only
+  // then can the hop's kept candidates hold one key twice, and its union needs the multiset rule
+  auto filter = [&](int arow, uint32_t loc, int old, bool clash, bool &twice) -> bool {
     const bool valid = is_valid(arow);
     const int tagged = (int)(tag | (uint32_t)arow);
     bool seen;
+    twice = false;
     if (WANN_LIKELY(!clash)) {
       // (a slot that holds this id already is left alone: the store would change nothing, and its line -- one 128-byte line of
       // HBM per neighbour: the filter of a beam-1 280 search is 2 MiB -- need not be written back.  Under load these searches
@@ -2058,6 +2061,16 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       seen = valid && (lower ? (prev_val == arow) : (old == tagged));
       if (valid && higher == 0) gtable[loc] = tagged;
       mark_written(valid && higher == 0, loc);
+      // does any lane's id repeat an earlier lane's of its slot class?
+      bool tw = false;
+      u64 lm = lower;
+      while (ballot64(lm != 0)) {
+        const int l = lm ? (63 - __builtin_clzll(lm)) : lane;
+        const int v = __shfl(arow, l);
+        if (lm && v == arow) tw = true;
+        if (lm) lm &= ~((u64)1 << l);
+      }
+      twice = uni((int)(ballot64(tw) != 0)) != 0;
     }
     const bool k = valid && !seen;
     ncmp_v += k ? 1 : 0;
@@ -2166,8 +2179,8 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       pm = ballot64(pass);
       WANN_PHASE(0);  // vectors + distances
       if (WANN_UNLIKELY(hop_exact)) {
-        // (lanes of this row shared a filter slot -- the row may list a node twice, and then the multiset union keeps two copies:
-        // this hop's candidates are united on their own)
+        // (this row lists a node twice within a slot class -- the multiset union may keep two copies of its key: the hop's
+        // candidates are united on their own)
         unite_pending();
         int p0;
         M = wave_merge(mb, M, B, pass, key, L.cand_key, &p0);
@@ -2213,8 +2226,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       pos_c = s1p;
       scan_from = s1p + 1;
       a_nx = s1a;
-      kept_nx = filter(s1a, s1loc, s1old, s1clash);
-      hop_exact = s1clash;
+      kept_nx = filter(s1a, s1loc, s1old, s1clash, hop_exact);
       if (prof) acc[5]++;
     } else {
       // ---- exact beam first; then the closest unvisited entry (beamSearch.h:108-117): entries before scan_from are visited
@@ -2261,8 +2273,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
         prepare(a_nx, loc, clash);
         old = probe(a_nx, loc);
       }
-      kept_nx = filter(a_nx, loc, old, clash);
-      hop_exact = clash;
+      kept_nx = filter(a_nx, loc, old, clash, hop_exact);
       load_window(pos_c + 1);
       WANN_PHASE(3);  // unexpected node / stale positions: union, scan, row, probes, filter
     }

@@ -1487,7 +1487,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       const bool kept = valid && !seen;  // what the reference scores
       ncmp_v += kept ? 1 : 0;
       const bool take = kept && !((sw >> (a & 31)) & 1u);  // what is computed
-      if (valid) gtable[loc] = tagged;
+      if (kept) gtable[loc] = tagged;  // (a slot that holds the id already is left alone: its line -- of a table of up to 32 MiB -- stays clean)
       if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, kSeenScope);
       WANN_PHASE(4);
       fetch_next();
@@ -1620,7 +1620,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     bool seen, twice = false;
     if (WANN_LIKELY(!clash)) {
       seen = valid && (old == tagged);
-      if (valid) gtable[loc] = tagged;
+      if (valid && !seen) gtable[loc] = tagged;
     } else {  // exact emulation of the sequential rule (as in wave_beam_search)
       u64 eq = ballot64(valid);
       for (int b = 0; b < bits; b++) {

@@ -669,6 +669,11 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
       HIP_CHECK(hipEventRecord(W.ev[nev], st));
       if (with_big) {  // first, so that its few workgroups are resident before the ordinary launch fills the CUs
         HIP_CHECK(hipStreamWaitEvent(side, W.ev[nev], 0));
+        if (T.profile_phases) {  // (make PROFILE=1 builds: the companion launch's phase cycles, i.e. the long chains UNDER the batch's load)
+          I.g_prof.ensure(16);
+          HIP_CHECK(hipMemsetAsync(I.g_prof.p, 0, 16 * sizeof(unsigned long long), side));
+          big.prof = I.g_prof.p;
+        }
         if (launch_search(big, big_lc, side)) throw HipError(std::string("k_search (big): ") + launch_last_error());
         HIP_CHECK(hipEventRecord(W.ev_side, side));
         // The deep-chain pollers book whole CUs, and nothing makes room for them once the ordinary launch has booked every
@@ -685,6 +690,13 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
                 rc.lc.big, rc.lc.blocks, rc.lc.waves_per_block, search_occupancy(a, rc.lc), a.pool_bytes, (long)first_beam, (long)cap, (long)items, with_big ? big_lc.blocks : 0,
                 with_big ? big.cap_inkernel : 0, with_big ? big.pool_bytes : 0, with_big ? big.npollers : 0);
       if (with_big) HIP_CHECK(hipStreamWaitEvent(st, W.ev_side, 0));
+      if (with_big && T.profile_phases) {
+        unsigned long long h[16];
+        HIP_CHECK(hipMemcpyAsync(h, I.g_prof.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        fprintf(stderr, "[wann companion phases] select %llu row+probes %llu next+requests %llu slot-test %llu filter %llu next-packet %llu distances %llu "
+                        "delta-insert %llu truncation %llu probe-wait %llu flush %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+      }
       HIP_CHECK(hipEventRecord(W.ev[nev + 1], st));
       timed.emplace_back(nev, nev + 1);
       nev += 2;

@@ -983,6 +983,12 @@ __device__ __forceinline__ u64 wave_shr1(u64 v) {  // lane i receives lane i-1's
 // chip with one L2 per XCD is performed beyond the L2 (fabric / memory side, > 1 us), and since a wave's vector-memory counter
 // retires in order every later load of the hop waited behind it.
 constexpr int kSeenScope = __HIP_MEMORY_SCOPE_WORKGROUP;
+// Packets are requested for the next WANN_BIG_LOOKAHEAD unvisited entries of the window (< kPkSlots - 2: request r + kPkSlots
+// reuses the slot of request r).  Measured on one box, SIFT-1M-like 2^-9 batch / lone beam-5120 search: 4 -> 11.82 / 8.33 ms,
+// 8 (with the filter store held back, see the fast path) -> 11.20 / 8.08 ms, 10 -> the same as 8.
+#ifndef WANN_BIG_LOOKAHEAD
+#define WANN_BIG_LOOKAHEAD 8
+#endif
 constexpr int kPkSlots = 12;
 constexpr int kReqRing = 16;
 static_assert(kPkSlots % kHelpers == 0 && kReqRing >= kPkSlots, "request -> helper / slot mapping");
@@ -1374,18 +1380,18 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       }
     }
   };
-  // packets are requested for the next four unvisited entries of the window
+  // packets are requested for the next WANN_BIG_LOOKAHEAD unvisited entries of the window
   auto request_packets = [&]() {
 #pragma unroll
     for (int r = 0; r < 2; r++) {  // (one per hop keeps the distance; two catch up after a restart)
-      if (r == 1 && WANN_LIKELY(nreq - rq_next >= 4)) break;
+      if (r == 1 && WANN_LIKELY(nreq - rq_next >= WANN_BIG_LOOKAHEAD)) break;
       u64 cand = wum;
       const int rel = req_pos - wbase;  // window bits <= rel have been requested
       if (rel >= 63) cand = 0;
       else if (rel >= 0) cand &= ~(((u64)2 << rel) - 1);
       if (!cand) break;
       const int j = ctz64(cand);
-      if (popc64(wum & (((u64)1 << j) - 1)) >= 4) break;
+      if (popc64(wum & (((u64)1 << j) - 1)) >= WANN_BIG_LOOKAHEAD) break;
       const int node = (int)((uint32_t)rdlane((int)(uint32_t)wv, j) >> 1);
       if (lane == 0) {
         vb->req[nreq & (kReqRing - 1)] = node;
@@ -1478,15 +1484,17 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       request_packets();
       WANN_PHASE(2);
       // lossy seen-filter (no shared slots in this row: the sequential rule is "old == id") + exact seen set
-      // (Measured, same box: the compiler issues the filter's store BEFORE it waits for the second probe, so that wait also
-      // covers the store's round trip -- the vector-memory counter retires in order -- and the phase takes 830 cycles; holding
-      // the store back behind the probes (an asm barrier) halves the phase and makes the whole search 5 % SLOWER: 9.66 vs
-      // 9.14 ms at beam 5 120.  Left as the compiler orders it.)
+      // (The compiler would issue the filter's store BEFORE it waits for the second probe; that wait then also covers the store's
+      // round trip -- the vector-memory counter retires in order --, i.e. two dependent round trips per hop: store, then the next
+      // hop's probes.  The empty asm below makes both probes "used" before the store.  Alone that is SLOWER -- the search wave
+      // outruns its helpers: 16 % of the hops without a packet instead of 7 % -- and with requests eight entries ahead instead of
+      // four it is faster: see WANN_BIG_LOOKAHEAD.)
       const int tagged = (int)(tag | (uint32_t)a);
       const bool seen = valid && (old == tagged);
       const bool kept = valid && !seen;  // what the reference scores
       ncmp_v += kept ? 1 : 0;
       const bool take = kept && !((sw >> (a & 31)) & 1u);  // what is computed
+      asm volatile("" ::"v"(sw), "v"(old));
       if (kept) gtable[loc] = tagged;  // (a slot that holds the id already is left alone: its line -- of a table of up to 32 MiB -- stays clean)
       if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, kSeenScope);
       WANN_PHASE(4);

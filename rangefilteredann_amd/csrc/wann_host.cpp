@@ -695,7 +695,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         HIP_CHECK(hipMemcpyAsync(h, I.g_prof.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         fprintf(stderr, "[wann companion phases] select %llu row+probes %llu next+requests %llu slot-test %llu filter %llu next-packet %llu distances %llu "
-                        "delta-insert %llu truncation %llu probe-wait %llu flush %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+                        "delta-insert %llu truncation %llu probe-wait %llu flush %llu; hops from the delta list %llu, window hops without a request %llu, with a request but no packet %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13]);
       }
       HIP_CHECK(hipEventRecord(W.ev[nev + 1], st));
       timed.emplace_back(nev, nev + 1);

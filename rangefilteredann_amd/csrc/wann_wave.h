@@ -1417,7 +1417,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     }
   };
 
-  unsigned long long tp = 0, acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tp = 0, acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (11 .. 13: hops from the delta list / window hops without a request / with a request but no packet yet)
 #define WANN_PHASE(i)                                       \
   do {                                                      \
     if (prof) {                                             \
@@ -1578,7 +1578,30 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       flags = nx_flags;
       valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
     } else {
-      if (!(box && consumed && read_packet(rq_next % kPkSlots, cur, a, loc, pk_dist, pk_mask, flags))) {
+      bool got = false;
+      if (box && consumed) got = read_packet(rq_next % kPkSlots, cur, a, loc, pk_dist, pk_mask, flags);
+      else if (box && !from_delta && nreq > 0) {
+        // An entry of the LDS beam whose request does not count any more: every merge of the delta list into the beam forgets the
+        // outstanding requests (new entries may sit between them), and the first hops after it found no packet -- one hop in
+        // twenty of a long search, each three dependent round trips of this wave (row, probes, vectors); half of them are
+        // found this way (2^-9 batch: hops without a packet 8.2 -> 6.0 %, 11.23 -> 10.98 ms).  The packets are
+        // still in their slots, though, tagged with their node: look the node up in the request ring (lane r reads ring
+        // entry r; entry r holds request idx, the last one issued with idx % kReqRing == r) and take the most recent hit
+        // whose packet is complete.
+        const int rn = lane < kReqRing ? vb->req[lane] : -1;
+        const int idx = nreq - 1 - ((nreq - 1 - lane) & (kReqRing - 1));
+        u64 hit = ballot64(lane < kReqRing && idx >= 0 && rn == cur);
+        while (hit && !got) {
+          int best = -1;
+          for (u64 hm = hit; hm; hm &= hm - 1) {
+            const int v = rdlane(idx, ctz64(hm));
+            best = v > best ? v : best;
+          }
+          got = read_packet(best % kPkSlots, cur, a, loc, pk_dist, pk_mask, flags);
+          hit &= ~((u64)1 << (best & (kReqRing - 1)));
+        }
+      }
+      if (!got) {
         if (lane < ix.rs) a = ix.graph[(row_base + cur) * (int64_t)ix.rs + lane];
         loc = (uint32_t)hash64_2((u64)(uint32_t)a) & tmask;
       }
@@ -1591,6 +1614,11 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     if (consumed) rq_next++;
     nx_node = -1;
     st_pk += (lane == 0 && (flags & 2)) ? 1 : 0;  // (lane-dependent on purpose: a statistic must not cost a scalar register)
+    if (prof) {
+      acc[11] += from_delta ? 1 : 0;
+      acc[12] += (!from_delta && !consumed) ? 1 : 0;
+      acc[13] += (!from_delta && consumed && !(flags & 2)) ? 1 : 0;
+    }
     WANN_PHASE(1);  // row, filter slots, probes
 
     // ---- the window follows the first unvisited entry
@@ -1712,7 +1740,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   }
   for (int o = 32; o; o >>= 1) ncmp_v += __shfl_xor(ncmp_v, o);
   if (prof && lane == 0)
-    for (int i = 0; i < 12; i++) atomicAdd(&prof[i], acc[i]);
+    for (int i = 0; i < 14; i++) atomicAdd(&prof[i], acc[i]);
   if (ctr && lane == 0) {
     atomicAdd(&ctr->big_searches, 1ull);
     atomicAdd(&ctr->big_hops, (unsigned long long)nvis);

@@ -262,7 +262,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=4, help="distinct query / window draws the timed steps rotate through (1 = the same batch every step)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
     ap.add_argument("--configs", default=None, help="N=1: the other BASELINE.json configurations as extra legs of the line: 'all' = glove "
-                    "(configs[2]), deep (configs[3] on this one GPU), adverse (configs[4]); 'none'; or a comma list")
+                    "(configs[2]), deep (configs[3] on this one GPU), adverse (configs[4]); 'none'; or a comma list (also: deep_l2 = configs[3] under squared L2)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -691,6 +691,9 @@ def other_configs(want, cache, ncpu):
         "deep": ("configs[3] (one GPU)", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "deep", "--threads", threads, "--seconds", "8",
                                           "--cache", os.path.join(cache, "cfg")]),
         "adverse": ("configs[4]", [os.path.join(REPO, "tools", "bench_prefilter.py")]),
+        # not part of "all" (two and a half more minutes): configs[3] under squared L2, as BASELINE.json's text states it
+        "deep_l2": ("configs[3] as its text states it (96-d L2; one GPU)", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "deep_l2", "--threads", threads,
+                                                                            "--seconds", "8", "--cache", os.path.join(cache, "cfg")]),
     }
     for name in want:
         if name not in legs:

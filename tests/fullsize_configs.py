@@ -18,6 +18,12 @@ CONFIGS = {
     # configs[3]: deep-10M-like, 4-ary tree (on ONE GPU here)
     "deep": dict(n=9_990_000, d=96, nq=10_000, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=4),
                  method="optimized_postfilter", graphs=True),
+    # configs[3] as BASELINE.json's text states it ("96-d L2"; the reference's own deep runs are inner product): the same rows and
+    # tree under squared L2 -- at full size (opt-in: two more minutes of build) and at n = 10^6 (always)
+    "deep_l2": dict(n=9_990_000, d=96, nq=10_000, cls="VamanaRangeFilterTreeIndexFloatEuclidian", kw=dict(cutoff=1000, split_factor=4),
+                    method="optimized_postfilter", graphs=True),
+    "deep_l2_1m": dict(n=1_000_000, d=96, nq=10_000, cls="VamanaRangeFilterTreeIndexFloatEuclidian", kw=dict(cutoff=1000, split_factor=4),
+                       method="optimized_postfilter", graphs=True),
     # configs[4]: adversarial clusters, stand-alone PrefilterIndex (dense MFMA path on native windows, exact scan on 2^-12 windows)
     "adverse": dict(n=1_000_000, d=100, nq=9_900, cls="PrefilterIndexFloatMips", kw={}, method=None, graphs=False),
 }
@@ -27,7 +33,7 @@ def make_data(name):
     import bench
     if name == "sift":
         return bench.make_data(1_000_000, 128, 10_000, 1)
-    if name in ("glove", "deep"):
+    if name in ("glove", "deep", "deep_l2", "deep_l2_1m"):
         from util import unit_mixture
         cfg = CONFIGS[name]
         g = unit_mixture(cfg["n"], cfg["d"], 2025)

@@ -98,6 +98,18 @@ def test_deep_10m_four_wst_rows_equal_the_reference(wa, gpu, tmp_path):
     _run_config(wa, "deep", (-6, -3), (80, 1), tmp_path)
 
 
+def test_deep_like_l2_four_wst_rows_equal_the_reference(wa, gpu, tmp_path):
+    """configs[3] as BASELINE.json's text states it -- "96-d L2" --: the deep-like rows and the 4-ary tree under squared L2 (the
+    12-block compile-time L2 routine of d = 96) against the real reference on the same graph files.  n = 10^6 always; the full
+    9 990 000 points with WANN_FULLSIZE_DEEP_L2=1 (two more minutes of build: `profiles/r05_config_deep_l2.json` is that run
+    through tools/bench_configs.py --config deep_l2)."""
+    full = os.environ.get("WANN_FULLSIZE_DEEP_L2", "0") == "1"
+    mem_gib = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2**30
+    if full and mem_gib < 160:
+        pytest.skip(f"{mem_gib:.0f} GiB of host memory: the full-size leg needs its 25 GB of graphs twice")
+    _run_config(wa, "deep_l2" if full else "deep_l2_1m", (-9, -6, -3), (80, 1), tmp_path)
+
+
 def test_sift_1m_two_wst_rows_equal_the_reference(wa, gpu, tmp_path):
     """configs[1]: n = 10^6, d = 128, squared L2, 2-WST, optimized_postfilter at the bench's setting (80, x1)"""
     # + the mid-fraction machinery where it is riskiest -- final re-searches (final_beam_multiply > 1) on chains that speculative

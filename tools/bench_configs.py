@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 CONFIGS = {
     "glove": dict(n=1_183_514, d=100, frac=-6, cls="SuperOptimizedPostfilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=2, shift_factor=0.5), method=None),
     "deep": dict(n=9_990_000, d=96, frac=-3, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=4), method="optimized_postfilter"),
+    # configs[3] as BASELINE.json's text states it ("96-d L2"): the same rows and tree under squared L2 (the reference itself runs
+    # deep-image-96-angular under inner product: experiments/run_our_method.py:218)
+    "deep_l2": dict(n=9_990_000, d=96, frac=-3, cls="VamanaRangeFilterTreeIndexFloatEuclidian", kw=dict(cutoff=1000, split_factor=4), method="optimized_postfilter"),
     # the other two query methods of the tree (range_filter_tree.h:297-401,473-540) at configs[1] size, unit-norm MIPS rows
     # (continuous coordinates: no distance ties, so rows must match exactly although both sides sort unstably)
     "fenwick": dict(n=1_000_000, d=100, frac=-6, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=2), method="fenwick"),
@@ -119,8 +122,12 @@ def main():
     Wt = torch.from_numpy(W).to(dev)
     gt = torch.empty((nq, K), dtype=torch.int64, device=dev)
     step = max(16, min(256, int(2**31 // (4 * n))))
-    for a in range(0, nq, step):  # exact filtered top-k (MIPS), inclusive bounds
+    l2 = cfg["cls"].endswith("Euclidian")
+    xn = (Xt * Xt).sum(1) if l2 else None
+    for a in range(0, nq, step):  # exact filtered top-k (inner product, or squared L2 up to the query's own norm), inclusive bounds
         s = -(Qt[a:a + step] @ Xt.T)
+        if l2:
+            s = s * 2 + xn[None, :]
         s.masked_fill_(~((labt[None, :] >= Wt[a:a + step, 0:1]) & (labt[None, :] <= Wt[a:a + step, 1:2])), float("inf"))
         gt[a:a + step] = torch.topk(s, K, dim=1, largest=False).indices
     del s
@@ -162,7 +169,7 @@ def main():
     c = index.counters()
     c["search_kernel_ms"] = sum(kernel_ms) / len(kernel_ms)  # mean over the timed calls (one call's figure varies by +-10 %)
     print(f"[cfg] counters of the last batch: {c}", file=sys.stderr, flush=True)
-    out = dict(config=args.config, workload=f"{cfg['cls']} n={n} d={d} MIPS R={R} L={L} {cfg['kw']} window 2^{cfg['frac']} nq={nq} k={K}",
+    out = dict(config=args.config, workload=f"{cfg['cls']} n={n} d={d} {'L2' if l2 else 'MIPS'} R={R} L={L} {cfg['kw']} window 2^{cfg['frac']} nq={nq} k={K}",
                build_s=round(build_s, 1), graphs=int(sum(levels)), levels=len(levels), index_gib=round(index.device_bytes() / 2**30, 2),
                setting=dict(beam=best["beam"], mult=best["mult"]), recall_at_10=round(recall(), 4), ms_per_batch=round(ms, 3), qps=round(nq / ms * 1e3),
                search_kernel_ms=round(c["search_kernel_ms"], 3), search_kernel_ms_per_call=[round(x, 3) for x in kernel_ms],
@@ -170,6 +177,8 @@ def main():
                sweep=rows, reference=[])
     if c["search_kernel_ms"] > 0:
         out["k_search_tb_per_s"] = round(out["algorithmic_gb_per_batch"] / c["search_kernel_ms"], 3)
+    if args.config == "deep_l2":
+        out["metric_note"] = "squared L2, as BASELINE.json configs[3]'s text states it; the reference's own deep runs are inner product (configs.deep)"
     if args.config == "deep":  # BASELINE.json's config text says "96-d L2"; the reference itself runs deep under inner product
         out["metric_note"] = "inner product, as the reference runs deep-image-96-angular (experiments/run_our_method.py:218 maps '*angular*' to mips)"
     # the asynchronous call, two batches in flight (wann_batch_search_device_async): does a second batch in flight buy anything on

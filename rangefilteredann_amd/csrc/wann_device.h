@@ -76,6 +76,7 @@ struct Counters {
   // one-wave kernel (wave_beam_search_big): searches, hops, hops served by a helper packet, hops with scoring in the search wave
   unsigned long long big_searches, big_hops, packet_hops, own_scorings, prefetched_hops;
   unsigned long long lookaheads_issued;  // look-ahead searches handed to pollers (used or not)
+  unsigned long long empty_windows;      // tree classes: queries whose window lies outside the index's label range (the reference prints a line for each)
 };
 
 struct RouteArgs {
@@ -118,7 +119,14 @@ struct RouteArgs {
   // k_search scan for chains that will outgrow their levels (may be null)
   int32_t *scan_list, *scan_count;
   Counters *ctr;
+  // QueryParams::verbose on the tree classes (range_filter_tree.h:452-457, super_optimized_postfilter_tree.h:226-249): what the
+  // descent of a query's window printed, as kVRouteWords words per query -- word 0 = words used, then entries of seven words
+  // (kind, index of the query's next task, five arguments): kind 1 "Testing bucket a", kind 2 "Query range = (a,b), smallest
+  // containing range (size e) = (c,d)", kind 3 the super tree's descent has ended (its two timing lines), kind 4 the
+  // Fenwick search's "Query range: a b" (range_filter_tree.h:363-366), kind 5 its "Searching bucket: a b" (:371-377).  Null otherwise.
+  int64_t *vroute;
 };
+constexpr int kVRouteWords = 1 + 7 * 40;
 
 struct SearchArgs {
   IndexView ix;

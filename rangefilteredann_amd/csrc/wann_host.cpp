@@ -443,6 +443,13 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   ra.scan_list = W.list_big.p + 3 * (size_t)W.big_stride;
   ra.scan_count = W.ints.p + I_SCAN_COUNT;
   ra.ctr = W.ctr.p;
+  const bool verbose_route = qp.verbose != 0 && (I.host().spec.kind == WANN_KIND_TREE_PREFILTER || I.host().spec.kind == WANN_KIND_TREE_VAMANA ||
+                                                   I.host().spec.kind == WANN_KIND_SUPER);
+  if (verbose_route) {
+    W.vroute.ensure((size_t)nq * kVRouteWords);
+    HIP_CHECK(hipMemsetAsync(W.vroute.p, 0, (size_t)nq * kVRouteWords * sizeof(int64_t), st));
+    ra.vroute = W.vroute.p;
+  }
   if (launch_route(ra, st)) throw HipError(std::string("k_route: ") + launch_last_error());
   // the list sizes come back while the exact scans run: the beam-search launches are sized by them, and skipped
   // altogether for batches without graph tasks (tiny windows) / without levels beyond the in-kernel cap
@@ -863,7 +870,25 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   HIP_CHECK(hipEventRecord(W.ev[1], st));
   HIP_CHECK(hipStreamSynchronize(st));
 
-  if (verbose_call && W.vlog.p) {
+  if (W.h_ctr->empty_windows) {
+    // range_filter_tree.h:191-203, super_optimized_postfilter_tree.h:173-184: the reference prints this line for every query whose
+    // window lies outside the index's label range -- verbose or not -- and returns no neighbours for it
+    std::vector<float> hr((size_t)nq * 2);
+    float ends[2];
+    HIP_CHECK(hipMemcpy(hr.data(), d_ranges, hr.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&ends[0], I.view.labels, sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&ends[1], I.view.labels + (I.view.n - 1), sizeof(float), hipMemcpyDeviceToHost));
+    // (Four significant digits where the leaves are Vamana graphs: building one makes ParlayANN's timer report, and that sets
+    // std::cout's precision to 4 and restores the flags only -- ParlayANN/algorithms/bench/get_time.h:59-68 -- so this is what a
+    // reference process prints after its index build; six digits otherwise.)
+    const int digits = I.host().vamana_leaves ? 4 : 6;
+    for (int64_t q = 0; q < nq; q++)
+      if (hr[2 * (size_t)q + 1] < ends[0] || hr[2 * (size_t)q] > ends[1])
+        printf("Query range is entirely outside the index range (%.*g, %.*g) index range vs. (%.*g, %.*g) This shouldn't happen but does not directly "
+               "impact correctness\n", digits, ends[0], digits, ends[1], digits, hr[2 * (size_t)q], digits, hr[2 * (size_t)q + 1]);
+    fflush(stdout);
+  }
+  if ((verbose_call && W.vlog.p) || verbose_route) {
     static std::mutex dump_mu;  // (WANN_DEVICES: one replica's dump at a time -- whole blocks, not interleaved lines)
     std::lock_guard<std::mutex> dump_lock(dump_mu);
     // the reference's dump (postfilter_vamana.h:155-185 + :230), per query and partition search, in query order
@@ -871,16 +896,49 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     constexpr int cap_v = kVlogCap;
     std::vector<Task> ht(nt);
     std::vector<int32_t> hq((size_t)nq), hn(nt);
-    std::vector<unsigned long long> hv(nt * cap_v);
+    std::vector<unsigned long long> hv(verbose_call && W.vlog.p ? nt * cap_v : 0);
     HIP_CHECK(hipMemcpy(ht.data(), W.tasks.p, nt * sizeof(Task), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(hq.data(), W.qtask_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(hn.data(), W.vlog_n.p, nt * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(hv.data(), W.vlog.p, hv.size() * 8, hipMemcpyDeviceToHost));
-    for (int64_t q = 0; q < nq; q++)
-      for (int i = 0; i < hq[(size_t)q]; i++) {
+    if (!hv.empty()) {  // (a tree with exact-scan leaves has no searches to dump: only the descent's lines)
+      HIP_CHECK(hipMemcpy(hn.data(), W.vlog_n.p, nt * 4, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(hv.data(), W.vlog.p, hv.size() * 8, hipMemcpyDeviceToHost));
+    }
+    // the tree classes' own lines around the searches (range_filter_tree.h:452-457, super_optimized_postfilter_tree.h:226-267):
+    // what the descent noted, printed before the task it led to.  The two timing lines of the super tree carry the batch's
+    // device time per query -- a query has no wall time of its own here.
+    std::vector<int64_t> hr;
+    if (verbose_route) {
+      hr.resize((size_t)nq * kVRouteWords);
+      HIP_CHECK(hipMemcpy(hr.data(), W.vroute.p, hr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    float batch_ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&batch_ms, W.ev[0], W.ev[1]));
+    const long long per_query_ns = (long long)(batch_ms * 1e6 / (double)std::max<int64_t>(nq, 1));
+    for (int64_t q = 0; q < nq; q++) {
+      const int64_t *rq = verbose_route ? hr.data() + (size_t)q * kVRouteWords : nullptr;
+      const int64_t rwords = rq ? rq[0] : 0;
+      bool timed_search = false;
+      auto route_lines = [&](int task_index) {  // (entries are in emission order)
+        for (int64_t o = 0; o + 7 <= rwords; o += 7) {
+          const int64_t *e = rq + 1 + o;
+          if (e[1] != task_index) continue;
+          if (e[0] == 1) printf("Testing bucket %lld\n", (long long)e[2]);
+          else if (e[0] == 2)
+            printf("Query range = (%lld,%lld), smallest containing range (size %lld) = (%lld,%lld)\n", (long long)e[2], (long long)e[3], (long long)e[6],
+                   (long long)e[4], (long long)e[5]);
+          else if (e[0] == 3) {
+            printf("Time to find bucket: 0ns\n");
+            timed_search = true;
+          } else if (e[0] == 4) printf("Query range: %lld %lld\n", (long long)e[2], (long long)e[3]);
+          else if (e[0] == 5) printf("Searching bucket: %lld %lld\n", (long long)e[2], (long long)e[3]);
+        }
+      };
+      for (int i = 0; i <= hq[(size_t)q]; i++) {
+        route_lines(i);
+        if (i == hq[(size_t)q]) break;
         const size_t ti = (size_t)q * maxt + i;
         const Task &t = ht[ti];
-        if (t.mode != T_GRAPH) continue;
+        if (t.mode != T_GRAPH || hv.empty()) continue;
         const long long mult = (t.flags & 2) ? 1 : (long long)qp.final_beam_multiply;
         printf("Starting optimized postfiltering, beam size = %lld, k = %lld, final multiply = %lld, n = %d\n", (long long)qp.beam_width,
                (long long)qp.k, mult, I.parts[(size_t)t.part].n);
@@ -913,6 +971,8 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         }
         printf("Final frontier size = %lld, final beam size %lld\n", frontier, beam);
       }
+      if (timed_search) printf("Time to do searcht: %lldns\n", per_query_ns);
+    }
     fflush(stdout);
   }
   float ms = 0.f;

@@ -64,6 +64,7 @@ struct Workspace {
   DevBuf<uint32_t> id_stage;
   DevBuf<unsigned long long> vlog;  // QueryParams::verbose: per-task records of the doubling loop (SearchArgs::vlog)
   DevBuf<int32_t> vlog_n;
+  DevBuf<int64_t> vroute;            // QueryParams::verbose on a tree class: the descent's dump (RouteArgs::vroute)
   DevBuf<int32_t> gat_send, gat_recv;  // wann_batch_search_allgather: this replica's [2][cap][k] planes / everybody's [world][2][cap][k]
   int32_t big_stride = 0;
   int32_t *h_ints = nullptr;  // pinned

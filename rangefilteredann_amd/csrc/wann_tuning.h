@@ -2,12 +2,18 @@
 //
 // The record is filled from the environment ONCE, when an index (or a raw graph) is created; the batch_search call never
 // reads the environment.  None of the switches changes a result row (the parity tests run them against each other).
-//   * scheduling / launch-shape knobs (WANN_NO_SPEC, WANN_POLLERS, WANN_HEAVY_RATIO ...) are honoured as found at creation;
-//   * hooks that exist only to force rare paths in tests (WANN_FORCE_POLLERS, WANN_FORCE_POLL_TIMEOUT, WANN_LA_EAGER,
-//     WANN_FORCE_GENERAL, WANN_OLD_GENERAL, WANN_RAW_BIG_LDS, WANN_BUILD_VIS_CAP) are ignored unless WANN_TEST_HOOKS=1;
-//   * with WANN_TEST_HOOKS=1 the entry points of the C ABI re-read the record before every call (tests flip switches
+//   * A PRODUCTION process honours three things: WANN_VERBOSE (launch lines on stderr), WANN_PROOF_FACTOR (can only widen the
+//     dense path's proof margin) and the HIP runtime's own serialisation variables.  (WANN_DEVICES -- which GPUs an index is
+//     replicated on -- is read by the C ABI, not here.)
+//   * EVERYTHING ELSE -- the scheduling / launch-shape knobs (WANN_NO_SPEC, WANN_POLLERS, WANN_HEAVY_RATIO ...) and the hooks that
+//     force rare paths in tests (WANN_FORCE_POLLERS, WANN_FORCE_POLL_TIMEOUT, WANN_LA_EAGER, WANN_FORCE_GENERAL,
+//     WANN_OLD_GENERAL, WANN_RAW_BIG_LDS, WANN_BUILD_VIS_CAP) -- is the laboratory: ignored unless WANN_TEST_HOOKS=1 (round 5; a
+//     development switch found in the environment without it is named once on stderr).  tests/conftest.py and the tools set it.
+//   * With WANN_TEST_HOOKS=1 the entry points of the C ABI also re-read the record before every call (tests flip switches
 //     between batches on one index); without it the record is fixed for the life of the index.
 #pragma once
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -63,13 +69,42 @@ struct Tuning {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
   }
+  // the laboratory: names that only count with WANN_TEST_HOOKS=1
+  static const char *const *lab_names() {
+    static const char *const names[] = {
+        "WANN_NO_SPEC", "WANN_NO_BIG", "WANN_NO_POLLERS", "WANN_NO_YIELD", "WANN_NO_HELPER", "WANN_NO_DEEP", "WANN_NO_GATE", "WANN_NO_LOOKAHEAD",
+        "WANN_SCAN", "WANN_NO_EVIDENCE_FIRST", "WANN_NO_ORDER", "WANN_NO_LEAN", "WANN_NO_SPLIT_SCAN", "WANN_NO_GEMM", "WANN_DENSE_ALWAYS",
+        "WANN_HEAVY_RATIO", "WANN_SPEC_NUM", "WANN_POLLERS", "WANN_DEEP_POLLERS", "WANN_DEEP_MIN_TASKS", "WANN_SCAN_NUM", "WANN_SCAN_MIN_TOP",
+        "WANN_BIG_EXCLUSIVE", "WANN_BLOCKS_PER_CU", "WANN_LEAN_POOL", "WANN_BRUTE_PER_CU", "WANN_SEARCH_PRIO", "WANN_FORCE_POLLERS",
+        "WANN_FORCE_POLL_TIMEOUT", "WANN_LA_EAGER", "WANN_FORCE_GENERAL", "WANN_OLD_GENERAL", "WANN_RAW_BIG_LDS", "WANN_PROFILE_PHASES",
+        "WANN_TASK_TRACE", nullptr};
+    return names;
+  }
   static Tuning from_env() {
     Tuning t;
     t.hooks_live = on("WANN_TEST_HOOKS");
+    t.serialized = on("HIP_LAUNCH_BLOCKING") || on("AMD_SERIALIZE_KERNEL") || on("CUDA_LAUNCH_BLOCKING");
+    t.verbose = set("WANN_VERBOSE");
+    // The proof's accumulation term: 3 = the truncating-adder bound (2 d u |q||p| per product term) and half as much again.
+    // A smaller factor would let k_rerank certify results it has not proven, so the knob can only WIDEN the margin.
+    if (const char *v = getenv("WANN_PROOF_FACTOR")) {
+      const float f = (float)atof(v);
+      t.proof_factor = (f == f && f > 3.f) ? f : 3.f;
+    }
+    if (!t.hooks_live) {
+      static std::atomic<bool> told{false};
+      if (!told.load(std::memory_order_relaxed)) {
+        std::string found;
+        for (const char *const *n = lab_names(); *n; n++)
+          if (getenv(*n)) found += std::string(found.empty() ? "" : ", ") + *n;
+        if (!found.empty() && !told.exchange(true))
+          fprintf(stderr, "[wann] development switch(es) in the environment are IGNORED without WANN_TEST_HOOKS=1: %s\n", found.c_str());
+      }
+      return t;
+    }
     t.spec = !set("WANN_NO_SPEC");
     t.big = !set("WANN_NO_BIG");
     t.pollers = !set("WANN_NO_POLLERS");
-    t.serialized = on("HIP_LAUNCH_BLOCKING") || on("AMD_SERIALIZE_KERNEL") || on("CUDA_LAUNCH_BLOCKING");
     t.yield = !set("WANN_NO_YIELD");
     t.helper = !set("WANN_NO_HELPER");
     t.deep = !set("WANN_NO_DEEP");
@@ -98,21 +133,12 @@ struct Tuning {
     t.lean_pool = num("WANN_LEAN_POOL", 0);
     t.brute_per_cu = num("WANN_BRUTE_PER_CU", 0);
     t.search_prio = num("WANN_SEARCH_PRIO", 0);
-    // The proof's accumulation term: 3 = the truncating-adder bound (2 d u |q||p| per product term) and half as much again.
-    // A smaller factor would let k_rerank certify results it has not proven, so the knob can only WIDEN the margin.
-    if (const char *v = getenv("WANN_PROOF_FACTOR")) {
-      const float f = (float)atof(v);
-      t.proof_factor = (f == f && f > 3.f) ? f : 3.f;
-    }
-    if (t.hooks_live) {
-      t.force_pollers = set("WANN_FORCE_POLLERS");
-      t.force_poll_timeout = set("WANN_FORCE_POLL_TIMEOUT");
-      t.la_eager = set("WANN_LA_EAGER");
-      t.force_general = set("WANN_FORCE_GENERAL");
-      t.old_general = set("WANN_OLD_GENERAL");
-      t.raw_big_lds = set("WANN_RAW_BIG_LDS");
-    }
-    t.verbose = set("WANN_VERBOSE");
+    t.force_pollers = set("WANN_FORCE_POLLERS");
+    t.force_poll_timeout = set("WANN_FORCE_POLL_TIMEOUT");
+    t.la_eager = set("WANN_LA_EAGER");
+    t.force_general = set("WANN_FORCE_GENERAL");
+    t.old_general = set("WANN_OLD_GENERAL");
+    t.raw_big_lds = set("WANN_RAW_BIG_LDS");
     t.profile_phases = set("WANN_PROFILE_PHASES");
     if (const char *v = getenv("WANN_TASK_TRACE")) t.task_trace = v;
     return t;

@@ -616,6 +616,10 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         if (use_pollers) {
           // (companion workgroups share their CUs: pollers are cheap; with the scan on, idle ones look for chains that need a look-ahead)
           a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : (T.npollers > 0 ? T.npollers : (scan_on ? 32 : 16));
+          // (the first npollers companion workgroups never touch the static list: with WANN_POLLERS >= the launch's workgroups
+          // nobody would search the speculated levels, and the tasks would resolve without them -- wrong rows, measured with
+          // WANN_POLLERS=256.  At least half of the workgroups always serve the list; they join the pollers when it is done.)
+          a.npollers = big.npollers = std::min<int32_t>(a.npollers, std::max(1, I.num_cus / 2));
           if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
           if (spec && T.lookahead) {  // look-ahead searches for chains that keep failing (k_search)
             a.la_count = big.la_count = W.ints.p + I_SUB_COUNT;

@@ -287,6 +287,8 @@ def main():
     os.environ.setdefault("PARLAY_NUM_THREADS", str(max(1, ncpu // world)))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["WANN_DEVICE"] = str(local_rank)
+    if args.pipeline > 2:  # (the asynchronous call's lanes are created at its first use: a lane per batch in flight)
+        os.environ["WANN_ASYNC_LANES"] = str(min(4, args.pipeline))
 
     import numpy as np
     import torch
@@ -518,7 +520,7 @@ def main():
     def pipelined_rate(qs, ws, qp_, nsteps, warm, ref_rows=None):
         """`nsteps` batches (rotating through qs / ws) through the asynchronous call, two in flight; optionally the rows of one more
         qs[0] / ws[0] batch against `ref_rows` (the blocking call's)."""
-        depth = 2
+        depth = max(2, min(4, args.pipeline))
 
         def go(ns):
             tickets, ctrs = [], []
@@ -547,9 +549,9 @@ def main():
         return rec
 
     if rank == 0 and world == 1 and args.pipeline >= 2:
-        pouts = [(torch.empty((nq, K), dtype=torch.int32, device=dev), torch.empty((nq, K), dtype=torch.float32, device=dev)) for _ in range(3)]
+        pouts = [(torch.empty((nq, K), dtype=torch.int32, device=dev), torch.empty((nq, K), dtype=torch.float32, device=dev)) for _ in range(max(3, args.pipeline + 1))]
         pipe = pipelined_rate([q[lo:hi] for q in rot_q], [w[lo:hi] for w in rot_w], qp_run, args.steps, args.warmup, (all_ids[lo:hi], all_d[lo:hi]))
-        log(f"pipelined (2 in flight): {pipe}")
+        log(f"pipelined: {pipe}")
 
     # the reference's own boundary (numpy in, numpy out): the same batch through the host-buffer entry point,
     # PCIe copies included -- reported beside `value`, never as `value`
@@ -647,7 +649,7 @@ def main():
                 # do two batches in flight buy anything where a batch ends with a few long chains?  (rows against the blocking call's)
                 run(Wpt[lo:hi], b["beam"], b["mult"])
                 blocking = (ids_t.clone(), dist_t.clone())
-                pr = pipelined_rate([Qt], [Wpt[lo:hi]], qparams(wa, b["beam"], b["mult"]), 6, 2, blocking)
+                pr = pipelined_rate([Qt], [Wpt[lo:hi]], qparams(wa, b["beam"], b["mult"]), 6 if args.pipeline <= 2 else 4 * args.pipeline, 2, blocking)
                 pr["speedup_over_blocking"] = round(b["wall_ms"] / pr["ms_per_step"], 3)
                 per[f"2^{p}"]["pipelined"] = pr
             log(f"  2^{p}: {per[f'2^{p}']}")

@@ -161,10 +161,11 @@ int wann_batch_search_device_ids(wann_index *index, const void *d_queries, const
 /* Asynchronous form of wann_batch_search_device (ABI 4).  The reference's call is blocking (src/range_filter_tree.h:62-96: it
  * returns when every query is answered) and so are the two calls above; a serving loop that answers batch after batch leaves
  * the GPU to the tail of one batch and the ramp-up of the next about a fifth of the time at 10 000 queries per batch.  This call
- * returns at once with a ticket: the batch runs on one of two LANES of the index (a lane = its own per-batch workspace, streams
+ * returns at once with a ticket: the batch runs on one of the LANES of the index (two; the environment variable WANN_ASYNC_LANES,
+ * 1 .. 4, read when the first asynchronous call creates them, sets another depth; a lane = its own per-batch workspace, streams
  * and host worker thread), ordered after the work the caller has queued on `after_stream` so far (its inputs; NULL = the HIP
  * default stream), and concurrently with the other lane's batch.  Same rows as the blocking call.  The output buffers belong
- * to the call until wann_wait(ticket) has returned; wait for ticket t before submitting ticket t + 2 (its lane is reused).
+ * to the call until wann_wait(ticket) has returned; wait for ticket t before submitting ticket t + <lanes> (its lane is reused).
  * wann_wait returns the batch's status (message in wann_last_error) and, if `counters` is not NULL, its work counters. */
 int wann_batch_search_device_async(wann_index *index, const void *d_queries, const float *d_ranges, int64_t nq,
                                    int64_t query_id_base, const char *method, const wann_query_params *qp, uint32_t *d_ids,

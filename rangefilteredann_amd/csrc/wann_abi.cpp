@@ -242,8 +242,14 @@ int wann_batch_search_device_ids(wann_index *I, const void *d_queries, const flo
   return WANN_OK;
 }
 
-// Asynchronous form of the device-buffer call (wann.h): tickets are served by kAsyncLanes lanes in turn.
-constexpr int kAsyncLanes = 2;
+// Asynchronous form of the device-buffer call (wann.h): tickets are served by the index's lanes in turn -- two by default,
+// WANN_ASYNC_LANES (1 .. 4, read when the first asynchronous call creates them) for deeper pipelines: a lane is a workspace, two
+// streams and a worker thread, and the batches in flight share the GPU.
+static int async_lane_count() {
+  const char *v = getenv("WANN_ASYNC_LANES");
+  const int n = v ? atoi(v) : 2;
+  return n < 1 ? 1 : n > 4 ? 4 : n;
+}
 
 int wann_batch_search_device_async(wann_index *I, const void *d_queries, const float *d_ranges, int64_t nq, int64_t query_id_base,
                                    const char *method, const wann_query_params *qp, uint32_t *d_ids, float *d_dists, void *after_stream,
@@ -262,7 +268,8 @@ int wann_batch_search_device_async(wann_index *I, const void *d_queries, const f
       if (I->lanes.empty()) {
         // (all lanes or none: a lane table that a failed creation left half filled would be indexed out of bounds by odd tickets)
         std::vector<std::unique_ptr<wann_index::AsyncLane>> fresh;
-        for (int l = 0; l < kAsyncLanes; l++) {
+        const int nl = async_lane_count();
+        for (int l = 0; l < nl; l++) {
           std::unique_ptr<wann_index::AsyncLane> L(new wann_index::AsyncLane);
           int prio_low = 0, prio_high = 0;
           HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
@@ -276,12 +283,12 @@ int wann_batch_search_device_async(wann_index *I, const void *d_queries, const f
         I->lanes.swap(fresh);
       }
       t = I->next_ticket;
-      Lp = I->lanes[(size_t)(t % kAsyncLanes)].get();
+      Lp = I->lanes[(size_t)(t % (int64_t)I->lanes.size())].get();
     }
     wann_index::AsyncLane &L = *Lp;
     {
       std::unique_lock<std::mutex> ll(L.m);
-      L.cv.wait(ll, [&] { return !L.busy; });  // (ticket t - kAsyncLanes has finished; wann_wait it BEFORE submitting this one to see its outcome)
+      L.cv.wait(ll, [&] { return !L.busy; });  // (ticket t - <number of lanes> has finished; wann_wait it BEFORE submitting this one to see its outcome)
       HIP_CHECK(hipEventRecord(L.ready, (hipStream_t)after_stream));
       L.job = wann_index::AsyncLane::Job{(const float *)d_queries, d_ranges, nq, query_id_base, method ? method : "", *qp, d_ids, d_dists, t, tune};
       L.has_job = true;
@@ -307,7 +314,7 @@ int wann_wait(wann_index *I, int64_t ticket, wann_counters *out) {
   {
     std::lock_guard<std::mutex> lk(I->lanes_mu);
     if (I->lanes.empty() || ticket >= I->next_ticket) return fail(WANN_ERR_INVALID, "wann_wait: no such ticket");
-    L = I->lanes[(size_t)(ticket % kAsyncLanes)].get();
+    L = I->lanes[(size_t)(ticket % (int64_t)I->lanes.size())].get();
   }
   std::unique_lock<std::mutex> ll(L->m);
   L->cv.wait(ll, [&] { return L->finished >= ticket; });

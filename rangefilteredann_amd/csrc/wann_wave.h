@@ -1772,8 +1772,11 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
 //    the closest unvisited entry of the whole beam and its rank there is its position, i.e. below B.  Otherwise the pending
 //    candidates are united first (ONE wave_merge for all of them) and the search goes on from the exact beam; so do the end of
 //    the search and the hop limit.  Between unions the cutoff is the LDS beam's last distance: never below the reference's,
-//    so a candidate the reference would have rejected may be admitted -- it sorts behind the reference's B-th entry, is never
-//    visited (rule above) and leaves at the next truncation.  Equal pending keys come from different hops (a hop without
+//    so a candidate the reference would have rejected may be admitted.  With a distance ABOVE the reference's B-th entry's it
+//    sorts behind that entry, is never visited (rule above) and leaves at the next truncation.  With an EQUAL distance and a
+//    smaller id it would sort before it and displace it (the reference rejects dist >= cutoff): a candidate at or above a
+//    lower bound of the true cutoff (the LDS beam's entry at B - 1 - D) whose distance equals that of an entry that may be
+//    the B-th one takes the exact path -- pending united first, test repeated.  Equal pending keys come from different hops (a hop without
 //    shared filter slots lists every node once), where the reference's per-hop union keeps one copy: wave_merge<COLLAPSE>;
 //    a hop WITH shared slots is united on its own, at once, with the multiset rule.
 //  * A HOP'S REQUESTS GO OUT TOGETHER, the vectors first; expectations, probes and the pending buffer are worked on while
@@ -2011,6 +2014,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
   int D = 0;
   u64 pmin = ~0ull;
   float cutoff = 2147483648.0f;  // (float)INT_MAX while the LDS beam is not full, else its last distance: never below the true cutoff
+  float lbv = 2147483648.0f;     // never above the true cutoff (set_lower_bound); equal to `cutoff` when nothing is pending
   // window: wv = mb[wbase + lane]; bit i of wum: entry wbase + i exists and is unvisited
   int wbase = 0;
   u64 wv = lane == 0 ? key0 : 1ull, wum = 1ull;
@@ -2116,6 +2120,13 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     cutoff = 2147483648.0f;
     if (M >= B) cutoff = funkey((uint32_t)(mb[M - 1] >> 32));
   };
+  // lbv (every lane the same value): a LOWER bound of the reference's cutoff while candidates are pending.  The reference's
+  // B-th entry is an entry of (LDS beam U pending); at most D pending keys sort before it, so it lies at or behind position
+  // B - 1 - D of the LDS beam.  No pending candidates, or fewer than B entries in all: the stale cutoff is the exact one.
+  auto set_lower_bound = [&]() {
+    lbv = cutoff;
+    if (D > 0 && M + D >= B) lbv = (B - 1 - D >= 0) ? funkey((uint32_t)(mb[B - 1 - D] >> 32)) : -__builtin_inff();
+  };
   // the pending candidates into the LDS beam (std::set_union + truncate, beamSearch.h:148-157, for all their hops at once)
   auto unite_pending = [&]() {
     if (D == 0) return;
@@ -2203,6 +2214,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     have = uni((int)have) != 0;
     hop_exact = uni((int)hop_exact) != 0;
     cutoff = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cutoff)));
+    lbv = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, lbv)));
 
     bool moved = false;  // the LDS beam changed in this iteration: positions and the window are stale
     bool pass = false;   // the finished hop's candidates (key / pass / pm): appended to the pending ones further down
@@ -2211,6 +2223,32 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
       // ---- the hop in flight: distances (beamSearch.h:135-145); what passes joins the pending candidates
       const float dist = mid_take_distances<METRIC, NBC>(ix, a, kept, row_off, L.qv, mode, rr, sc_r, sc_nt, sc_touch);
       pass = kept && (dist < cutoff);
+      // `cutoff` is the LDS beam's: stale while candidates are pending.  A candidate in [true cutoff, cutoff) is admitted though the
+      // reference rejects it (beamSearch.h:135-145: dist >= cutoff); it does no harm when it sorts BEHIND the reference's B-th
+      // entry -- never visited, gone at the next truncation -- i.e. unless its distance EQUALS that entry's and its id is
+      // smaller (tie-heavy data: small integer coordinates, duplicate rows).  The B-th entry is one of the LDS beam's entries
+      // from position B - 1 - D on or a pending one: a candidate at or above the lower bound whose distance equals one of
+      // theirs sends the hop down the exact path -- the pending candidates are united first and the test is repeated against
+      // the exact cutoff.
+      const u64 amb = ballot64(pass && dist >= lbv);
+      if (WANN_UNLIKELY(amb != 0)) {
+        WAVE_SYNC();
+        const float qn = __builtin_nanf("");
+        const int from = B - 1 - D > 0 ? B - 1 - D : 0;
+        const float pd = lane < D ? funkey((uint32_t)(pend[lane] >> 32)) : qn;
+        const float t0 = from + lane < M ? funkey((uint32_t)(mb[from + lane] >> 32)) : qn;
+        const float t1 = from + 64 + lane < M ? funkey((uint32_t)(mb[from + 64 + lane] >> 32)) : qn;
+        bool tie = false;
+        for (u64 mm = amb; mm; mm &= mm - 1) {
+          const float dc = __builtin_bit_cast(float, rdlane(__builtin_bit_cast(int, dist), ctz64(mm)));
+          tie = tie || pd == dc || t0 == dc || t1 == dc;
+        }
+        if (ballot64(tie) != 0) {
+          unite_pending();
+          moved = true;
+          pass = kept && (dist < cutoff);
+        }
+      }
       key = ((u64)fkey(dist) << 32) | ((u64)(uint32_t)a << 1);
       pm = ballot64(pass);
       WANN_PHASE(0);  // vectors + distances
@@ -2323,6 +2361,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
     WANN_PHASE(6);  // vector requests
     expect();
     if (committed) append();
+    set_lower_bound();
     a = a_nx;
     kept = kept_nx;
     have = true;

@@ -93,6 +93,39 @@ def test_raw_beam_search_core_variants(oracle, wa, gpu, monkeypatch, env, metric
             assert int(hops[i]) == len(vi) and int(cmps[i]) == dc, (beam, i, hops[i], len(vi), cmps[i], dc)
 
 
+@pytest.mark.parametrize("env", [{}, {"WANN_FORCE_GENERAL": "1"}, {"WANN_RAW_BIG_LDS": "1", "WANN_FORCE_GENERAL": "1"}],
+                         ids=lambda e: "+".join(sorted(e)) or "default")
+@pytest.mark.parametrize("metric", [0, 1])
+def test_raw_beam_search_on_tie_heavy_data(oracle, wa, gpu, monkeypatch, env, metric):
+    """Small integer coordinates (d = 6, values below 12) and duplicate rows: most distances are shared by many nodes, so a candidate
+    whose distance EQUALS the beam's last entry's is the common case.  The reference rejects it (beamSearch.h:135-145: dist >= cutoff);
+    a core that tests candidates against a cutoff that is not the exact one admits it, and with a smaller id it then displaces the
+    B-th entry (the third-generation core's deferred union).  Ids, distances, hops and dist_cmps against the oracle at
+    beams on both sides of every core boundary."""
+    n, nq, R, L, d = 4000, 48, 32, 64, 6
+    rng = np.random.default_rng(99)
+    X = rng.integers(0, 12, size=(n, d)).astype(np.float32)
+    X[rng.choice(n, 600, replace=False)] = X[rng.choice(n, 600)]  # duplicate rows
+    Q = rng.integers(0, 12, size=(nq, d)).astype(np.float32)
+    Q[::4] = X[rng.choice(n, len(Q[::4]))]                        # queries that ARE points
+    Xp = oracle.pad_rows(X)
+    start, sn = 200, 3600
+    rows = oracle.vamana_build(Xp, d, metric, start, sn, R, L, 1.0)
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    qids = np.arange(nq, dtype=np.int64) + 10**6
+    bad = []
+    for beam in (20, 64, 100, 130, 160, 250, 320, 640, 1000, 1280, 2000):
+        ids, dists, sizes, hops, cmps = wa.raw_beam_search(metric, X, rows, start, Q, qids, beam)
+        for i in range(nq):
+            oi, od, vi, vd, dc = oracle.beam_search(rows, Xp, d, metric, start, Q[i], int(qids[i]), beam)
+            m = int(sizes[i])
+            if not (m == len(oi) and np.array_equal(ids[i, :m], oi) and np.array_equal(dists[i, :m], od)
+                    and int(hops[i]) == len(vi) and int(cmps[i]) == dc):
+                bad.append((beam, i, m, len(oi), int(hops[i]), len(vi), int(cmps[i]), dc))
+    assert not bad, (len(bad), bad[:10])
+
+
 @pytest.mark.parametrize("metric,gen,d,R", [(0, sift_like, 64, 96), (1, unit_mixture, 100, 128), (0, unit_mixture, 40, 80)])
 def test_raw_beam_search_on_wide_rows(oracle, wa, gpu, metric, gen, d, R):
     """64 < max_degree <= 128 (graph.h:115-124 takes any R): rows of up to 128 neighbours, worked in two halves per hop, against

@@ -5,7 +5,7 @@
 // (a lane pair per row, 16 bytes per lane and load, 16 loads per lane) plus 256-byte adjacency rows (4 bytes per lane).  This
 // program issues exactly that, with a known byte count, from a buffer far larger than the 256 MiB Infinity Cache:
 //
-//   gather_calib <buffer_GiB> <rows_per_launch> <row_bytes> <launches> [hot_MiB]
+//   gather_calib <buffer_GiB> <rows_per_launch> <row_bytes> <launches> [hot_MiB]      (row_bytes 4: single-dword random probes)
 //
 // rows are drawn uniformly from the whole buffer -- or, with hot_MiB > 0, from a window of that size (to see what the counter
 // does when the working set fits the L2 / the Infinity Cache).  Prints one JSON line: bytes per launch (rows x row_bytes), mean
@@ -65,6 +65,21 @@ __global__ __launch_bounds__(256) void k_gather_rows256(const int *buf, uint64_t
   if (acc == 12345) sink[0] = acc;
 }
 
+// filter probes: every lane reads ONE dword at a random address of its own (64 different 128-byte lines per wave-instruction) --
+// the seen-filter probes of a mid-beam search (a table of 4 << bits bytes per search: 2 MiB at beam 1 280)
+__global__ __launch_bounds__(256) void k_probe4(const int *buf, uint64_t nwords, uint64_t probes, uint64_t seed, int *sink) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * blockDim.x;
+  int acc = 0;
+  for (uint64_t r0 = t * 8; r0 < probes; r0 += nt * 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = buf[mix(seed + r0 + u) % nwords];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += v[u];
+  }
+  if (acc == 12345) sink[0] = acc;
+}
+
 int main(int argc, char **argv) {
   const double gib = argc > 1 ? atof(argv[1]) : 2.0;
   const uint64_t rows = argc > 2 ? strtoull(argv[2], nullptr, 10) : 34000000ull;
@@ -90,8 +105,9 @@ int main(int argc, char **argv) {
     else if (row_bytes == 384) hipLaunchKernelGGL(k_gather<12>, dim3(blocks), dim3(256), 0, nullptr, (const float4 *)buf, nrows_buf, rows, seed, (float *)sink);
     else if (row_bytes == 448) hipLaunchKernelGGL(k_gather<14>, dim3(blocks), dim3(256), 0, nullptr, (const float4 *)buf, nrows_buf, rows, seed, (float *)sink);
     else if (row_bytes == 256) hipLaunchKernelGGL(k_gather_rows256, dim3(blocks), dim3(256), 0, nullptr, (const int *)buf, nrows_buf, rows, seed, (int *)sink);
+    else if (row_bytes == 4) hipLaunchKernelGGL(k_probe4, dim3(blocks), dim3(256), 0, nullptr, (const int *)buf, nrows_buf, rows, seed, (int *)sink);
     else {
-      fprintf(stderr, "row_bytes must be 512, 448, 384 or 256\n");
+      fprintf(stderr, "row_bytes must be 512, 448, 384, 256 or 4 (single-dword probes)\n");
       exit(2);
     }
   };

@@ -154,34 +154,43 @@ def levels_from_costs(costs: Sequence[float], beam: int, cap: int = 8) -> List[i
 def _deal_and_gather(items, run_group, world: int, rank: int, k: int, dev, group):
     """items: list of (query, beam, max_beam, mult), the SAME list on every rank.  Item i is searched by rank i % world after the
     items are ordered longest search first (every rank gets a fair share of every length class); run_group(query_numbers, beam, max_beam,
-    mult) -> (ids, dists) serves the items of one setting.  ONE all-gather returns every item's row to every rank."""
+    mult) -> (ids, dists) serves the items of one setting.  ONE all-gather returns every item's row to every rank:
+    (ids (len(items), k) int32, dists (len(items), k) float32), row i = item i.  `dev` None: the device of run_group's rows."""
     order = sorted(range(len(items)), key=lambda i: (-items[i][1], items[i][2], items[i][3], items[i][0]))
     mine = [i for pos, i in enumerate(order) if pos % world == rank]
-    cap = (len(items) + world - 1) // world
-    send = torch.zeros((2, max(cap, 1), k), dtype=torch.int32, device=dev)
+    cap = max((len(items) + world - 1) // world, 1)
     by_setting = {}
     for slot, i in enumerate(mine):
         by_setting.setdefault(items[i][1:], []).append((slot, items[i][0]))
+    send = None
     for (beam, max_beam, mult), lst in sorted(by_setting.items(), reverse=True):
         qn = torch.tensor([q for _, q in lst], dtype=torch.int64, device=dev)
         ids, dists = run_group(qn, int(beam), int(max_beam), int(mult))[:2]
+        if send is None:
+            dev = ids.device if dev is None else dev
+            send = torch.zeros((2, cap, k), dtype=torch.int32, device=dev)
         slots = torch.tensor([s for s, _ in lst], dtype=torch.int64, device=dev)
-        send[0, slots] = ids.view(torch.int32)
-        send[1, slots] = dists.view(torch.int32)
+        send[0].index_copy_(0, slots, ids.view(torch.int32).to(dev))
+        send[1].index_copy_(0, slots, dists.view(torch.int32).to(dev))
+    if send is None:  # (this rank was dealt nothing: more ranks than items)
+        if dev is None:
+            dev = torch.device("cuda", torch.cuda.current_device()) if (world > 1 and dist.get_backend(group) == "nccl") else torch.device("cpu")
+        send = torch.zeros((2, cap, k), dtype=torch.int32, device=dev)
     if world == 1:
         recv = send.unsqueeze(0)
     else:
-        recv = torch.empty((world, 2, max(cap, 1), k), dtype=torch.int32, device=dev)
+        recv = torch.empty((world, 2, cap, k), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(recv.view(-1, k), send.view(-1, k), group=group)
-    rows = {}
-    for pos, i in enumerate(order):
-        r, slot = pos % world, pos // world
-        rows[i] = (recv[r, 0, slot], recv[r, 1, slot].view(torch.float32))
-    return rows
+    # item order[pos] sits in plane pos % world, slot pos // world
+    pos_of = torch.empty(len(items), dtype=torch.int64)
+    pos_of[torch.tensor(order, dtype=torch.int64)] = torch.arange(len(items), dtype=torch.int64)
+    pos_of = pos_of.to(dev)
+    r_of, s_of = pos_of % world, pos_of // world
+    return recv[r_of, 0, s_of], recv[r_of, 1, s_of].view(torch.float32), dev
 
 
 def level_dealt_batch_search(run_group: Callable, nq: int, k: int, beam: int, max_beam: int, mult: int, levels: Sequence[int], device=None,
-                             group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                             group=None, method: str = "optimized_postfilter", min_query_to_bucket_ratio=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """The batch of `sharded_batch_search`, cut for STRONG scaling: what a rank takes is not a range of queries but single searches.
 
     The reference's doubling loop (src/postfilter_vamana.h:161-181) searches a query's partition at beam, 2 beam, 4 beam ... -- every
@@ -195,63 +204,79 @@ def level_dealt_batch_search(run_group: Callable, nq: int, k: int, beam: int, ma
     batch_search over THOSE queries of the batch -- each under its own global number (`wann_batch_search_device_ids`; the reference's
     "a query's own id is its row number" quirk, beamSearch.h:128) -- with QueryParams(k, beam, ..., multiply, max_beam).  A single
     level is run_group(q, b, b + 1, 1): with max_beam = b + 1 the loop searches once at b and neither doubles nor re-searches.
-    Query classes whose batch_search is ONE post-filter chain per query (optimized_postfilter on a tree, the super tree, the
-    stand-alone post filter) -- tiny windows that take the exact scan return the same rows at every level and settle at the first."""
+
+    ONLY for query classes whose batch_search is ONE post-filter chain per query: optimized_postfilter on a tree WITHOUT
+    `min_query_to_bucket_ratio` (with it a query may fall back to the several-chain fenwick search, range_filter_tree.h:460-466), the
+    super tree, the stand-alone post filter -- anything else raises ValueError (use `sharded_batch_search`).  Tiny windows that take
+    the exact scan return the same rows at every level and settle at the first.  `device`: where the gathered rows live (default:
+    the device of run_group's rows).  The sequential rule runs as tensor operations: one host copy of the per-query decision."""
+    if method not in ("optimized_postfilter", "super_optimized_postfilter", "postfilter", "") or min_query_to_bucket_ratio is not None:
+        raise ValueError("level_dealt_batch_search serves one post-filter chain per query: not the fenwick / three_split methods and not "
+                         "optimized_postfilter with min_query_to_bucket_ratio (range_filter_tree.h:460-466); use sharded_batch_search")
     grouped = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if grouped else 1
     rank = dist.get_rank(group) if grouped else 0
     if len(levels) != nq:
         raise ValueError("one level count per query")
     beam, max_beam, mult = int(beam), int(max_beam), int(mult)
-
-    def searched_levels(q):  # levels of query q that the loop can reach at all: beam << r < max_beam
-        n = 0
-        while n < int(levels[q]) and (beam << n) < max_beam:
-            n += 1
-        return n
+    # levels of query q that the loop can reach at all: beam << r < max_beam
+    reach = 0
+    while (beam << reach) < max_beam:
+        reach += 1
+    nlev = [min(int(l), reach) for l in levels]
     # ---- phase A: whole chains of the queries with one predicted level, single levels of the others
-    items, where = [], {}
+    items = []
+    Lmax = max([1] + nlev)
+    item_of = torch.full((nq, Lmax), -1, dtype=torch.int64)  # item of (query, level); whole chains: column 0
     for q in range(nq):
-        L = searched_levels(q)
+        L = nlev[q]
         if L <= 1:
-            where[(q, -1)] = len(items)
+            item_of[q, 0] = len(items)
             items.append((q, beam, max_beam, mult))
         else:
             for r in range(L):
-                where[(q, r)] = len(items)
+                item_of[q, r] = len(items)
                 items.append((q, beam << r, (beam << r) + 1, 1))
-    rows = _deal_and_gather(items, run_group, world, rank, k, device, group)
-    out_ids = torch.empty((nq, k), dtype=torch.int32, device=device)
-    out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
-    # ---- the sequential rule, then phase B
+    ids_a, d_a, dev = _deal_and_gather(items, run_group, world, rank, k, device, group)
+    out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    if nq == 0:
+        return out_ids, out_d
+    # ---- the sequential rule (tensor operations on the gathered rows), then phase B
+    item_dev = item_of.to(dev)
+    nlev_t = torch.tensor(nlev, dtype=torch.int64, device=dev)
+    multi = nlev_t > 1
+    found_item = (d_a < FLT_MAX).sum(1) >= k                                   # per item: its final beam held k in-window entries
+    found = found_item[item_dev.clamp(min=0)] & (item_dev >= 0) & multi[:, None]  # (nq, Lmax)
+    any_hit = found.any(1)
+    hit = torch.where(any_hit, found.to(torch.int64).argmax(1), torch.full_like(nlev_t, -1))
+    # which phase-A item holds a query's row if no second phase is needed: its whole chain, its first successful level, or -- every
+    # level short and the loop at its end -- its last level
+    settle_level = torch.where(multi, torch.where(any_hit, hit, nlev_t - 1), torch.zeros_like(nlev_t))
+    settle_item = item_dev.gather(1, settle_level[:, None]).squeeze(1)
+    out_ids.copy_(ids_a.index_select(0, settle_item))
+    out_d.copy_(d_a.index_select(0, settle_item))
+    hit_h = hit.cpu().tolist()  # the one host copy: phase B's item list is built on the host (the same on every rank)
     items_b, target = [], []
     for q in range(nq):
-        if (q, -1) in where:
-            out_ids[q], out_d[q] = rows[where[(q, -1)]]
+        L = nlev[q]
+        if L <= 1:
             continue
-        L = searched_levels(q)
-        hit = None
-        for r in range(L):
-            if int((rows[where[(q, r)]][1] < FLT_MAX).sum()) >= k:
-                hit = r
-                break
-        if hit is not None:  # :173-181: the final re-search, if its beam exceeds the level's
-            b = beam << hit
+        if hit_h[q] >= 0:  # :173-181: the final re-search, if its beam exceeds the level's
+            b = beam << hit_h[q]
             fb = min(b * mult, max_beam)
             if fb > b:
                 items_b.append((q, fb, fb + 1, 1))
                 target.append(q)
-            else:
-                out_ids[q], out_d[q] = rows[where[(q, hit)]]
         else:  # every searched level was short: the loop carries on at beam << L -- if that is still below max_beam
             b = beam << L
             if b < max_beam:
                 items_b.append((q, b, max_beam, mult))
                 target.append(q)
-            else:  # (the loop ends with the last level's short rows; min(b * mult, max_beam) <= b: no re-search)
-                out_ids[q], out_d[q] = rows[where[(q, L - 1)]]
-    if items_b:  # (the same list on every rank: it follows from the gathered rows)
-        rows_b = _deal_and_gather(items_b, run_group, world, rank, k, device, group)
-        for i, q in enumerate(target):
-            out_ids[q], out_d[q] = rows_b[i]
+            # (else the loop ends with the last level's short rows; min(b * mult, max_beam) <= b: no re-search)
+    if items_b:
+        ids_b, d_b, _ = _deal_and_gather(items_b, run_group, world, rank, k, dev, group)
+        tq = torch.tensor(target, dtype=torch.int64, device=dev)
+        out_ids.index_copy_(0, tq, ids_b)
+        out_d.index_copy_(0, tq, d_b)
     return out_ids, out_d

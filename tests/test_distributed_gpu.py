@@ -1,6 +1,7 @@
-"""GPU: the N > 1 product path on the RCCL backend.  The GPU box has one device, so the process group has ONE rank:
-`nccl` is initialised, sharded_batch_search drives the HIP kernels and its all-gather runs over RCCL; rows must equal
-the unsharded call.  Also: bench.py under the driver's launch line with one rank prints a line with n_gpus = 1."""
+"""GPU: the N > 1 product path on the RCCL backend -- sharded_batch_search / level_dealt_batch_search drive the HIP kernels on
+every rank and their all-gathers run over RCCL; rows must equal the single-GPU call.  With ONE device the process group has one
+rank (the collective still runs); on a box with more GPUs the same worker runs with 2 .. 8 ranks (it SKIPS LOUDLY on one GPU).
+Also: bench.py under the driver's launch line with one rank prints a line with n_gpus = 1."""
 import json
 import os
 import subprocess
@@ -19,17 +20,32 @@ def _env():
     return env
 
 
-def _torchrun(script, *args):
+def _torchrun(script, *args, ranks=1):
     sys.path.insert(0, REPO)
     import bench
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
             "--master-port", str(bench.free_port()), script] + list(args)
 
 
-def test_sharded_batch_search_on_nccl_world_1(gpu):
-    out = subprocess.run(_torchrun(os.path.join(REPO, "tests", "nccl_world1_worker.py")), capture_output=True, text=True,
-                         timeout=900, env=_env())
-    assert out.returncode == 0 and "NCCL_WORLD1_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+def _run_worker(ranks):
+    out = subprocess.run(_torchrun(os.path.join(REPO, "tests", "nccl_worker.py"), str(ranks), ranks=ranks), capture_output=True, text=True,
+                         timeout=1500, env=_env())
+    assert out.returncode == 0 and f"NCCL_WORKER_OK world={ranks}" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_sharded_and_level_dealt_search_on_nccl_world_1(gpu):
+    _run_worker(1)
+
+
+@pytest.mark.parametrize("ranks", [2, 4, 8])
+def test_sharded_and_level_dealt_search_on_nccl_multi_rank(gpu, wa, ranks):
+    """One process per GPU, `ranks` of them: RCCL sees `ranks` ranks (asserted inside every rank), every rank runs the HIP engine on
+    its own replica, rows are compared with the single-GPU call on every rank."""
+    have = wa.device_count()
+    if have < ranks:
+        pytest.skip(f"NOT EXERCISED: the {ranks}-rank RCCL path needs {ranks} GPUs and this box has {have} "
+                    "(the multi-rank collectives are covered on gloo by tests/test_distributed_cpu.py only)")
+    _run_worker(ranks)
 
 
 def test_bench_under_the_launcher_with_one_rank(gpu, tmp_path):

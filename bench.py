@@ -262,7 +262,8 @@ def main():
     ap.add_argument("--rotate", type=int, default=4, help="distinct query / window draws the timed steps rotate through (1 = the same batch every step)")
     ap.add_argument("--cache", default=os.environ.get("WANN_BENCH_CACHE", "/tmp/wann_bench_cache"))
     ap.add_argument("--configs", default=None, help="N=1: the other BASELINE.json configurations as extra legs of the line: 'all' = glove "
-                    "(configs[2]), deep (configs[3] on this one GPU), adverse (configs[4]); 'none'; or a comma list (also: deep_l2 = configs[3] under squared L2)")
+                    "(configs[2]), deep (configs[3] on this one GPU), adverse (configs[4]), sift_u8 / fenwick / three_split (SURVEY.md 8(f)-4 / 8(f)-2 at "
+                    "configs[1] size); 'none'; or a comma list (also: deep_l2 = configs[3] under squared L2)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -668,10 +669,10 @@ def main():
 
     # ---- the other BASELINE.json configurations (parity cases at full size; each in a child process with its own index)
     if rank == 0 and world == 1 and args.configs != "none":
-        want = ["glove", "deep", "adverse"] if args.configs == "all" else [c for c in args.configs.split(",") if c]
+        want = ["glove", "deep", "adverse", "sift_u8", "fenwick", "three_split"] if args.configs == "all" else [c for c in args.configs.split(",") if c]
         del index, Xt, x2, labt  # HBM and host memory for the children's own data (deep: 24.6 GB of index)
         torch.cuda.empty_cache()
-        result["configs"] = other_configs(want, args.cache, ncpu)
+        result["configs"] = other_configs(want, args.cache, ncpu, cache if args.workload == "sift" and n == 1_000_000 and d == 128 else None)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -679,7 +680,7 @@ def main():
         dist.destroy_process_group()
 
 
-def other_configs(want, cache, ncpu):
+def other_configs(want, cache, ncpu, sift_cache=None):
     """BASELINE.json configs[2] (GloVe-like super tree, 2^-6), configs[3] (deep-10M-like 4-WST, 2^-3, here on ONE GPU) and
     configs[4] (adversarial data, PrefilterIndex on the dense MFMA path) as child processes (tools/bench_configs.py,
     tools/bench_prefilter.py): each builds its index on the GPU, sweeps against exact ground truth, times the best setting
@@ -687,12 +688,21 @@ def other_configs(want, cache, ncpu):
     import subprocess
     out = {}
     threads = str(min(32, ncpu))
+    # (sift_u8 starts from the graph files the headline run left in its cache: the same graphs, see tools/bench_configs.py)
+    child_env = dict(os.environ, WANN_BENCH_SIFT_CACHE=sift_cache) if sift_cache else None
     legs = {
         "glove": ("configs[2]", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "glove", "--threads", threads, "--seconds", "8",
                                  "--cache", os.path.join(cache, "cfg")]),
         "deep": ("configs[3] (one GPU)", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "deep", "--threads", threads, "--seconds", "8",
                                           "--cache", os.path.join(cache, "cfg")]),
         "adverse": ("configs[4]", [os.path.join(REPO, "tools", "bench_prefilter.py")]),
+        # SURVEY.md 8(f)-2 / 8(f)-4, at configs[1] size: the tree's other two query methods and the byte variant of the headline workload
+        "fenwick": ("8(f)-2: fenwick query method (range_filter_tree.h:297-401), 2-WST n=10^6", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "fenwick",
+                    "--threads", threads, "--seconds", "6", "--cache", os.path.join(cache, "cfg")]),
+        "three_split": ("8(f)-2: three_split query method (range_filter_tree.h:473-540), 2-WST n=10^6", [os.path.join(REPO, "tools", "bench_configs.py"), "--config",
+                        "three_split", "--threads", threads, "--seconds", "6", "--cache", os.path.join(cache, "cfg")]),
+        "sift_u8": ("8(f)-4: configs[1] with uint8 points (python_bindings.cpp:234-237)", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "sift_u8",
+                    "--threads", threads, "--seconds", "6", "--cache", os.path.join(cache, "cfg")]),
         # not part of "all" (two and a half more minutes): configs[3] under squared L2, as BASELINE.json's text states it
         "deep_l2": ("configs[3] as its text states it (96-d L2; one GPU)", [os.path.join(REPO, "tools", "bench_configs.py"), "--config", "deep_l2", "--threads", threads,
                                                                             "--seconds", "8", "--cache", os.path.join(cache, "cfg")]),
@@ -703,7 +713,7 @@ def other_configs(want, cache, ncpu):
         label, cmd = legs[name]
         t0 = time.time()
         try:
-            p = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=1500)
+            p = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=1500, env=child_env)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode != 0 or not line:
                 raise RuntimeError((p.stderr or "")[-600:])

@@ -422,7 +422,8 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
   ra.spec = spec ? 1 : 0;
   ra.spec_num = T.spec_num;
-  ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp.beam_width);
+  const int64_t inkernel_cap = T.inkernel_cap > 0 ? T.inkernel_cap : kInKernelBeamCap;
+  ra.cap_inkernel = (int32_t)std::max<int64_t>(inkernel_cap, qp.beam_width);
   ra.sub_base0 = (int32_t)(nq * maxt);
   ra.sub_cap = (int32_t)(nq * maxt + sub_slots);
   ra.sub_count = W.ints.p + I_SUB_COUNT;
@@ -715,7 +716,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     };
     // launch 1: every task, in-kernel doubling up to kInKernelBeamCap (long tasks first)
     const int64_t b0 = qp.beam_width;
-    const int64_t cap1 = std::max<int64_t>(kInKernelBeamCap, b0);
+    const int64_t cap1 = std::max<int64_t>(inkernel_cap, b0);
     sa.list = W.list_a.p;
     sa.list_count = W.ints.p + I_GRAPH_COUNT;
     sa.heavy_list = sa.prio_list = W.list_heavy.p;
@@ -746,7 +747,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     // Three workgroups per CU (a leaner LDS pool) where the kernel allows it and no companion workgroup has to share a CU with
     // the ordinary ones (the deep-chain pollers book whole CUs of their own)
     int base_pool = kSearchPoolBytes;
-    if (big_n == 0 && !may_continue && T.lean && cap1 == kInKernelBeamCap && lean_pool_bytes(I, T) > 0) base_pool = lean_pool_bytes(I, T);
+    if (big_n == 0 && !may_continue && T.lean && cap1 <= kInKernelBeamCap && lean_pool_bytes(I, T) > 0) base_pool = lean_pool_bytes(I, T);
     // How many: with two workgroups per CU (squared-L2 float kernel) four -- 16 cost the SIFT-1M 2^-3 batch 2.5 %; with three
     // (twelve waves share a CU's memory path: a third level takes 2.2 ms there, 1.5 ms on a poller) every third-level chain
     // should find one: 16 (deep-10M-like, eight such chains: 5.3 -> 4.5 ms per batch; 12 ... 32 measure alike).

@@ -51,6 +51,7 @@ struct Tuning {
   int lean_pool = 0;           // WANN_LEAN_POOL (0: computed)
   int brute_per_cu = 0;        // WANN_BRUTE_PER_CU (0: by element type)
   int search_prio = 0;         // WANN_SEARCH_PRIO
+  int inkernel_cap = 0;        // WANN_INKERNEL_CAP (0: kInKernelBeamCap): largest beam of the four-wave kernel; levels above go to the companion launch
   float proof_factor = 3.f;    // WANN_PROOF_FACTOR, clamped to >= 3 (see dense_prefilter)
   // test-only hooks (WANN_TEST_HOOKS=1)
   bool force_pollers = false, force_poll_timeout = false, la_eager = false, force_general = false, old_general = false,
@@ -75,7 +76,7 @@ struct Tuning {
         "WANN_NO_SPEC", "WANN_NO_BIG", "WANN_NO_POLLERS", "WANN_NO_YIELD", "WANN_NO_HELPER", "WANN_NO_DEEP", "WANN_NO_GATE", "WANN_NO_LOOKAHEAD",
         "WANN_SCAN", "WANN_NO_EVIDENCE_FIRST", "WANN_NO_ORDER", "WANN_NO_LEAN", "WANN_NO_SPLIT_SCAN", "WANN_NO_GEMM", "WANN_DENSE_ALWAYS",
         "WANN_HEAVY_RATIO", "WANN_SPEC_NUM", "WANN_POLLERS", "WANN_DEEP_POLLERS", "WANN_DEEP_MIN_TASKS", "WANN_SCAN_NUM", "WANN_SCAN_MIN_TOP",
-        "WANN_BIG_EXCLUSIVE", "WANN_BLOCKS_PER_CU", "WANN_LEAN_POOL", "WANN_BRUTE_PER_CU", "WANN_SEARCH_PRIO", "WANN_FORCE_POLLERS",
+        "WANN_BIG_EXCLUSIVE", "WANN_INKERNEL_CAP", "WANN_BLOCKS_PER_CU", "WANN_LEAN_POOL", "WANN_BRUTE_PER_CU", "WANN_SEARCH_PRIO", "WANN_FORCE_POLLERS",
         "WANN_FORCE_POLL_TIMEOUT", "WANN_LA_EAGER", "WANN_FORCE_GENERAL", "WANN_OLD_GENERAL", "WANN_RAW_BIG_LDS", "WANN_PROFILE_PHASES",
         "WANN_TASK_TRACE", nullptr};
     return names;
@@ -133,6 +134,8 @@ struct Tuning {
     t.lean_pool = num("WANN_LEAN_POOL", 0);
     t.brute_per_cu = num("WANN_BRUTE_PER_CU", 0);
     t.search_prio = num("WANN_SEARCH_PRIO", 0);
+    t.inkernel_cap = num("WANN_INKERNEL_CAP", 0);
+    if (t.inkernel_cap < 0 || t.inkernel_cap > 1280) t.inkernel_cap = 0;  // (the four-wave kernel's LDS pool holds beams up to 1 280)
     t.force_pollers = set("WANN_FORCE_POLLERS");
     t.force_poll_timeout = set("WANN_FORCE_POLL_TIMEOUT");
     t.la_eager = set("WANN_LA_EAGER");

@@ -31,12 +31,21 @@ CONFIGS = {
     # (continuous coordinates: no distance ties, so rows must match exactly although both sides sort unstably)
     "fenwick": dict(n=1_000_000, d=100, frac=-6, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=2), method="fenwick"),
     "three_split": dict(n=1_000_000, d=100, frac=-6, cls="VamanaRangeFilterTreeIndexFloatMips", kw=dict(cutoff=1000, split_factor=2), method="three_split"),
+    # configs[1]'s points, queries, tree and window fraction with the points held as BYTES (python_bindings.cpp:234-237: the
+    # UInt8Euclidian variant; euclidian_point.h:44-60: int32 accumulation cast to float): a quarter of the vector traffic per
+    # scored neighbour, the adjacency rows unchanged
+    "sift_u8": dict(n=1_000_000, d=128, frac=-3, cls="VamanaRangeFilterTreeIndexUInt8Euclidian", kw=dict(cutoff=1000, split_factor=2),
+                    method="optimized_postfilter", law="sift", dtype="uint8"),
 }
 R, L, ALPHA, K = 64, 500, 1.0, 10
 
 
 def make(cfg, n, nq):
     import numpy as np
+    if cfg.get("law") == "sift":  # bench.py's SIFT-1M-like law and seeds (integer values 0 .. 255: exact as bytes)
+        import bench
+        X, Q, labels = bench.make_data(n, cfg["d"], nq, 1)
+        return X.astype(cfg["dtype"]), Q.astype(cfg["dtype"]), labels
     from util import unit_mixture
     g = unit_mixture(n, cfg["d"], 2025)
     X, Q = g(n), g(nq)
@@ -106,6 +115,10 @@ def main():
     X, Q, labels = make(cfg, n, nq)
     print(f"[cfg] {args.config}: data n={n} d={d} in {time.time() - t0:.1f}s; host {os.cpu_count()} cpus, {mem_gib:.0f} GiB", file=sys.stderr, flush=True)
     cache = os.path.join(args.cache, f"{'tree1m' if args.config in ('fenwick', 'three_split') else args.config}_n{n}") + "/"
+    if args.config == "sift_u8" and os.environ.get("WANN_BENCH_SIFT_CACHE"):
+        # bench.py's float32 index of the same points: on integer-valued data the byte and float32 builds make the same graphs
+        # (exact arithmetic either way), so the leg may start from the graph files the headline run left behind
+        cache = os.environ["WANN_BENCH_SIFT_CACHE"]
     os.makedirs(cache, exist_ok=True)
     t0 = time.time()
     index = getattr(wa, cfg["cls"])(X, labels, build_params=wa.BuildParams(R, L, ALPHA, cache), **cfg["kw"])
@@ -114,7 +127,9 @@ def main():
     print(f"[cfg] index ready in {build_s:.1f}s: {sum(levels)} graphs in {len(levels)} levels, {index.device_bytes() / 2**30:.2f} GiB in HBM", file=sys.stderr, flush=True)
 
     dev = torch.device("cuda:0")
-    Xt, labt, Qt = torch.from_numpy(X).to(dev), torch.from_numpy(labels).to(dev), torch.from_numpy(Q).to(dev)
+    # (device-resident queries of a byte index are float32 rows of integer values: include/wann.h)
+    Xt, labt, Qt = torch.from_numpy(X.astype(np.float32)).to(dev), torch.from_numpy(labels).to(dev), torch.from_numpy(Q.astype(np.float32)).to(dev)
+    esz = X.dtype.itemsize  # bytes per coordinate in HBM
     ls = np.sort(labels)
     w = int(n * 2.0 ** cfg["frac"])
     st = np.random.default_rng(5).integers(1, n - w - 1, size=nq)
@@ -173,7 +188,7 @@ def main():
                build_s=round(build_s, 1), graphs=int(sum(levels)), levels=len(levels), index_gib=round(index.device_bytes() / 2**30, 2),
                setting=dict(beam=best["beam"], mult=best["mult"]), recall_at_10=round(recall(), 4), ms_per_batch=round(ms, 3), qps=round(nq / ms * 1e3),
                search_kernel_ms=round(c["search_kernel_ms"], 3), search_kernel_ms_per_call=[round(x, 3) for x in kernel_ms],
-               algorithmic_gb_per_batch=round((4 * (R + 1) * c["hops"] + 4 * d * c["dist_cmps"] + 4 * c["label_reads"]) / 1e9, 3),
+               algorithmic_gb_per_batch=round((4 * (R + 1) * c["hops"] + esz * d * (c["dist_cmps"] + c["brute_rows"]) + 4 * c["label_reads"]) / 1e9, 3),
                sweep=rows, reference=[])
     if c["search_kernel_ms"] > 0:
         out["k_search_tb_per_s"] = round(out["algorithmic_gb_per_batch"] / c["search_kernel_ms"], 3)

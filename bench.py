@@ -646,6 +646,12 @@ def main():
                                  # over the WHOLE call's device time, against the 8 TB/s HBM peak
                                  algorithmic_gb=round(b["alg_bytes"] / 1e9, 3),
                                  roofline_frac=round(b["alg_bytes"] / (b["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b["device_ms"] > 0 else None)
+            # HBM bytes of the batch from the committed counter pass of this very leg (profiles/*_pmc_traffic.json), if there is one
+            tr_p, src_p = measured_traffic(b["beam"], b["mult"], n, nq, p)
+            per[f"2^{p}"]["traffic"] = tr_p
+            if tr_p is not None:
+                per[f"2^{p}"]["traffic_source"] = src_p
+                per[f"2^{p}"]["traffic_over_algorithmic"] = round(tr_p / b["alg_bytes"], 3) if b["alg_bytes"] else None
             if pouts is not None and p in (-9, -6):
                 # do two batches in flight buy anything where a batch ends with a few long chains?  (rows against the blocking call's)
                 run(Wpt[lo:hi], b["beam"], b["mult"])

@@ -208,14 +208,18 @@ def level_dealt_batch_search(run_group: Callable, nq: int, k: int, beam: int, ma
     ONLY for query classes whose batch_search is ONE post-filter chain per query: optimized_postfilter on a tree WITHOUT
     `min_query_to_bucket_ratio` (with it a query may fall back to the several-chain fenwick search, range_filter_tree.h:460-466), the
     super tree, the stand-alone post filter -- anything else raises ValueError (use `sharded_batch_search`).  Tiny windows that take
-    the exact scan return the same rows at every level and settle at the first.  `device`: where the gathered rows live (default:
-    the device of run_group's rows).  The sequential rule runs as tensor operations: one host copy of the per-query decision."""
+    the exact scan return the same rows at every level and settle at the first.  `device`: where the query numbers handed to run_group
+    and the gathered rows live (default: the current GPU under an `nccl` group, else the device of run_group's rows -- run_group then
+    receives its query numbers on the CPU).  The sequential rule runs as tensor operations: one host copy of the per-query decision."""
     if method not in ("optimized_postfilter", "super_optimized_postfilter", "postfilter", "") or min_query_to_bucket_ratio is not None:
         raise ValueError("level_dealt_batch_search serves one post-filter chain per query: not the fenwick / three_split methods and not "
                          "optimized_postfilter with min_query_to_bucket_ratio (range_filter_tree.h:460-466); use sharded_batch_search")
     grouped = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if grouped else 1
     rank = dist.get_rank(group) if grouped else 0
+    if device is None and grouped and dist.get_backend(group) == "nccl":
+        # (RCCL moves device memory only; run_group is handed its query numbers on this device too)
+        device = torch.device("cuda", torch.cuda.current_device())
     if len(levels) != nq:
         raise ValueError("one level count per query")
     beam, max_beam, mult = int(beam), int(max_beam), int(mult)

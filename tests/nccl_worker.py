@@ -76,7 +76,7 @@ def main():
             idx.batch_search_device_ids(qs.data_ptr(), ws.data_ptr(), qn.shape[0], qn.contiguous().data_ptr(), method,
                                         wa.QueryParams(k, b, 1.35, 10_000_000, 10_000, m, mb, None, False), ri.data_ptr(), rd.data_ptr(), 0)
             return ri, rd
-        gi, gd = level_dealt_batch_search(run_group, nq, k, beam, 10000, mult, levels_from_costs(costs, beam), method=method)
+        gi, gd = level_dealt_batch_search(run_group, nq, k, beam, 10000, mult, levels_from_costs(costs, beam), device=dev, method=method)
         ok &= same(gi, gd, "level_dealt_batch_search")
     if world == 1:
         # the 8-rank cut, replayed shard by shard on this GPU: shards keep their global query numbers

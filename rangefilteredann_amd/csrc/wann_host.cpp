@@ -473,6 +473,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   I.dense_batches++;
 
   const bool may_brute = I.host().spec.kind != WANN_KIND_POSTFILTER && I.host().spec.kind != WANN_KIND_SUPER;
+  bool scans_aside = false;
   if (may_brute) {
     BruteArgs ba{};
     ba.ix = I.view;
@@ -485,6 +486,18 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     ba.out_key = W.out_key.p;
     ba.out_cnt = W.out_cnt.p;
     ba.ctr = W.ctr.p;
+    // fenwick / three_split (range_filter_tree.h:297-401,473-540): every query has end scans AND graph searches -- up to two leaf-sized
+    // scans per query, a streaming read of ~8 GB per 10 000 queries at n = 10^6 -- and the two touch different task slots.  The scans
+    // run beside the searches on a stream of their own (they were 0.7 ms of a 3 ms batch in front of k_search); k_finalize_multi waits
+    // for both.  Batches of the one-task methods keep the single stream (their scans are the tiny windows' and mostly absent).
+    scans_aside = maxt > 1 && sized;
+    hipStream_t scan_st = st;
+    if (scans_aside) {
+      if (!W.scan_stream) HIP_CHECK(hipStreamCreateWithFlags(&W.scan_stream, hipStreamNonBlocking));
+      if (!W.ev_scan) HIP_CHECK(hipEventCreateWithFlags(&W.ev_scan, hipEventDisableTiming));
+      scan_st = W.scan_stream;
+      HIP_CHECK(hipStreamWaitEvent(scan_st, W.ev_route, 0));  // (recorded behind k_route and this batch's clears)
+    }
     if (T.split_scan) {
       const size_t part_cap = (size_t)4 << 20, part_slots = 8192;  // 32 MiB of partial lists
       // (a list is only split while it has far fewer entries than there are waves)
@@ -492,7 +505,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
       W.part_cnt.ensure(part_slots);
       W.part_done.ensure(part_slots);
       // the kernel leaves zeros behind -- unless a batch ended in an error: 32 KB per batch buy that certainty
-      HIP_CHECK(hipMemsetAsync(W.part_done.p, 0, W.part_done.cap * sizeof(int32_t), st));
+      HIP_CHECK(hipMemsetAsync(W.part_done.p, 0, W.part_done.cap * sizeof(int32_t), scan_st));
       ba.part_key = W.part_key.p;
       ba.part_cnt = W.part_cnt.p;
       ba.part_done = W.part_done.p;
@@ -504,7 +517,8 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     const int brute_per_cu = T.brute_per_cu > 0 ? T.brute_per_cu  // dev knob
                              : (I.view.dtype != WANN_DTYPE_F32 ? 5 : (I.view.metric == 1 ? 3 : 2));
     int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * brute_per_cu, (nq * std::min(maxt, 2) + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (launch_brute(ba, blocks, st)) throw HipError(std::string("k_brute: ") + launch_last_error());
+    if (launch_brute(ba, blocks, scan_st)) throw HipError(std::string("k_brute: ") + launch_last_error());
+    if (scans_aside) HIP_CHECK(hipEventRecord(W.ev_scan, scan_st));
   }
 
   int rounds = 0, nev = 2;
@@ -855,6 +869,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     }
   }
 
+  if (scans_aside) HIP_CHECK(hipStreamWaitEvent(st, W.ev_scan, 0));
   FinalizeArgs fa{};
   fa.ix = I.view;
   fa.tasks = W.tasks.p;

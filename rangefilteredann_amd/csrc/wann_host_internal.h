@@ -72,12 +72,17 @@ struct Workspace {
   std::vector<hipEvent_t> ev;
   hipEvent_t ev_side = nullptr;   // end of the companion (big) launch on the index's side stream
   hipEvent_t ev_route = nullptr;  // list sizes of k_route are on the host
+  // fenwick / three_split: the end scans (k_brute) run BESIDE the graph searches of the same batch on a stream of the lane's own
+  hipStream_t scan_stream = nullptr;
+  hipEvent_t ev_scan = nullptr;
   ~Workspace() {
     if (h_ints) (void)hipHostFree(h_ints);
     if (h_ctr) (void)hipHostFree(h_ctr);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (ev_side) (void)hipEventDestroy(ev_side);
     if (ev_route) (void)hipEventDestroy(ev_route);
+    if (ev_scan) (void)hipEventDestroy(ev_scan);
+    if (scan_stream) (void)hipStreamDestroy(scan_stream);
   }
   void ensure(int64_t nq, int k, int maxt, int64_t sub_slots) {
     const size_t nt = (size_t)nq * maxt + (size_t)sub_slots;

@@ -188,7 +188,7 @@ def main():
                build_s=round(build_s, 1), graphs=int(sum(levels)), levels=len(levels), index_gib=round(index.device_bytes() / 2**30, 2),
                setting=dict(beam=best["beam"], mult=best["mult"]), recall_at_10=round(recall(), 4), ms_per_batch=round(ms, 3), qps=round(nq / ms * 1e3),
                search_kernel_ms=round(c["search_kernel_ms"], 3), search_kernel_ms_per_call=[round(x, 3) for x in kernel_ms],
-               algorithmic_gb_per_batch=round((4 * (R + 1) * c["hops"] + esz * d * (c["dist_cmps"] + c["brute_rows"]) + 4 * c["label_reads"]) / 1e9, 3),
+               algorithmic_gb_per_batch=round((4 * (R + 1) * c["hops"] + esz * d * c["dist_cmps"] + 4 * c["label_reads"]) / 1e9, 3),  # (k_search's bytes: the end scans of fenwick / three_split are k_brute's)
                sweep=rows, reference=[])
     if c["search_kernel_ms"] > 0:
         out["k_search_tb_per_s"] = round(out["algorithmic_gb_per_batch"] / c["search_kernel_ms"], 3)

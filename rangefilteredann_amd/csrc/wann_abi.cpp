@@ -495,6 +495,7 @@ int wann_predict_costs(wann_index *I, const float *ranges, int64_t nq, const cha
     ra.brute_count = W.ints.p + I_BRUTE_COUNT;
     ra.spec = 0;  // (plain tasks only: each carries its window's size)
     ra.spec_num = tune.spec_num;
+    ra.spec_extra = tune.spec_extra;
     ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp->beam_width);
     ra.sub_base0 = ra.sub_cap = (int32_t)(nq * maxt);
     ra.sub_count = W.ints.p + I_SUB_COUNT;

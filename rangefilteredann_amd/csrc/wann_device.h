@@ -107,6 +107,8 @@ struct RouteArgs {
   // in the slots [sub_base0, sub_cap); the parent is resolved by whichever sub-task finishes last
   int32_t spec;         // 0 = off
   int32_t spec_num;     // spawn levels up to the first beam with beam * w / n_p >= k * spec_num / 8
+  int32_t spec_extra;   // >= 3: a task with at least that many predicted levels whose last level expects fewer than 2 k in-window entries
+                        // gets the next level too, if the four-wave kernel runs it (0: never)
   int32_t cap_inkernel;
   int32_t sub_base0, sub_cap;
   int32_t *sub_count;   // next free sub-task slot (relative to sub_base0)

@@ -422,6 +422,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
   ra.spec = spec ? 1 : 0;
   ra.spec_num = T.spec_num;
+  ra.spec_extra = T.spec_extra;
   const int64_t inkernel_cap = T.inkernel_cap > 0 ? T.inkernel_cap : kInKernelBeamCap;
   ra.cap_inkernel = (int32_t)std::max<int64_t>(inkernel_cap, qp.beam_width);
   ra.sub_base0 = (int32_t)(nq * maxt);

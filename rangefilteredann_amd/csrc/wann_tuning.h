@@ -41,6 +41,7 @@ struct Tuning {
   bool dense_always = false;   // WANN_DENSE_ALWAYS
   int heavy_ratio = 8;         // WANN_HEAVY_RATIO
   int spec_num = 8;            // WANN_SPEC_NUM
+  int spec_extra = 0;          // WANN_SPEC_EXTRA (see RouteArgs::spec_extra)
   int npollers = 0;            // WANN_POLLERS (0: 32 with the scan, else 16)
   int deep_pollers = 0;        // WANN_DEEP_POLLERS (0: 4, or 16 where three workgroups share a CU)
   long long deep_min_tasks = 4096;  // WANN_DEEP_MIN_TASKS
@@ -75,7 +76,7 @@ struct Tuning {
     static const char *const names[] = {
         "WANN_NO_SPEC", "WANN_NO_BIG", "WANN_NO_POLLERS", "WANN_NO_YIELD", "WANN_NO_HELPER", "WANN_NO_DEEP", "WANN_NO_GATE", "WANN_NO_LOOKAHEAD",
         "WANN_SCAN", "WANN_NO_EVIDENCE_FIRST", "WANN_NO_ORDER", "WANN_NO_LEAN", "WANN_NO_SPLIT_SCAN", "WANN_NO_GEMM", "WANN_DENSE_ALWAYS",
-        "WANN_HEAVY_RATIO", "WANN_SPEC_NUM", "WANN_POLLERS", "WANN_DEEP_POLLERS", "WANN_DEEP_MIN_TASKS", "WANN_SCAN_NUM", "WANN_SCAN_MIN_TOP",
+        "WANN_HEAVY_RATIO", "WANN_SPEC_NUM", "WANN_SPEC_EXTRA", "WANN_POLLERS", "WANN_DEEP_POLLERS", "WANN_DEEP_MIN_TASKS", "WANN_SCAN_NUM", "WANN_SCAN_MIN_TOP",
         "WANN_BIG_EXCLUSIVE", "WANN_INKERNEL_CAP", "WANN_BLOCKS_PER_CU", "WANN_LEAN_POOL", "WANN_BRUTE_PER_CU", "WANN_SEARCH_PRIO", "WANN_FORCE_POLLERS",
         "WANN_FORCE_POLL_TIMEOUT", "WANN_LA_EAGER", "WANN_FORCE_GENERAL", "WANN_OLD_GENERAL", "WANN_RAW_BIG_LDS", "WANN_PROFILE_PHASES",
         "WANN_TASK_TRACE", nullptr};
@@ -122,6 +123,7 @@ struct Tuning {
     if (t.heavy_ratio < 1) t.heavy_ratio = 1;
     t.spec_num = num("WANN_SPEC_NUM", 8);
     if (t.spec_num < 1) t.spec_num = 1;
+    t.spec_extra = num("WANN_SPEC_EXTRA", 0);
     t.npollers = num("WANN_POLLERS", 0);
     if (t.npollers < 0) t.npollers = 0;
     t.deep_pollers = num("WANN_DEEP_POLLERS", 0);

@@ -785,7 +785,8 @@ def measured_traffic(beam, mult, n, nq_per_gpu, fraction=-3):
             pj = json.load(open(os.path.join(prof, name)))
         except Exception:
             continue
-        if (pj.get("beam") == beam and pj.get("mult") == mult and pj.get("n") == n and pj.get("nq", 10_000) == nq_per_gpu
+        # (a fraction whose windows all take the exact scan moves the same bytes at every setting)
+        if (((pj.get("beam") == beam and pj.get("mult") == mult) or pj.get("scan_only")) and pj.get("n") == n and pj.get("nq", 10_000) == nq_per_gpu
                 and pj.get("fraction", -3) == fraction):
             best = (pj.get("hbm_bytes_per_launch"), f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE pass of this configuration, not this run)")
     return best if best else (None, None)

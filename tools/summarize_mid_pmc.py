@@ -13,9 +13,9 @@ def counters(p):
     for f in glob.glob(os.path.join(src, f"pmc{p}_g*", "**", "*counter_collection.csv.sel.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            if "k_search" not in kn:
+            if "k_search" not in kn and "k_brute" not in kn:
                 continue
-            kind = kn[kn.index("k_search"):].split("(")[0]
+            kind = kn[kn.index("k_search" if "k_search" in kn else "k_brute"):].split("(")[0]
             acc.setdefault(kind, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return acc
 
@@ -57,13 +57,15 @@ for p in sys.argv[3:]:
                 if nm in rec:
                     rec[nm + "_share_of_wave_cycles"] = round(rec[nm]["median"] / wc, 4)
         per_kernel[kind] = rec
-    alg = line["roofline"]["algorithmic_bytes_per_step"] if line else None
+    alg = line["roofline"]["algorithmic_bytes_per_step"] if line else None  # (graph rows + scored vectors + labels; exact scans are not in it)
     out = dict(
-        what=f"SIFT-1M-like 2-WST, window fraction 2^{p}, setting (80, x1), 10 000 queries: rocprofv3 --pmc passes (one counter group per run) of "
-             "bench.py --fractions headline --fraction p --setting 80,1 --pipeline 0.  Under --pmc the runtime serialises dispatches: the companion launch "
+        what=f"SIFT-1M-like 2-WST, window fraction 2^{p}, 10 000 queries, the setting named below: rocprofv3 --pmc passes (one counter group per run) of "
+             "bench.py --fractions headline --fraction p --setting beam,mult --pipeline 0.  Under --pmc the runtime serialises dispatches: the companion launch "
              "(k_search<0, 1>) runs BEFORE the ordinary one instead of beside it, its pollers give up, and continuations / look-aheads run in "
              "follow-up launches -- the bytes are those of the batch, the kernels' durations are not the concurrent batch's",
-        kernel="k_search<0, 0> + k_search<0, 1> (sum per batch)", n=1_000_000, nq=10_000, fraction=int(p), beam=80, mult=1,
+        kernel=" + ".join(sorted(per_kernel)) + " (sum per batch)", n=1_000_000, nq=10_000, fraction=int(p),
+        beam=line["config"]["beam"] if line else 80, mult=line["config"]["final_beam_multiply"] if line else 1,
+        scan_only=bool(line and line["roofline"]["hops_per_step"] == 0),  # (every window takes the exact scan: the setting changes nothing)
         correction="FETCH_SIZE (KiB) x 1024 x 2: TCC_EA0_RDREQ_32B is 0 in every pass, i.e. every request is a full line; bytes = RDREQ x 128 B "
                    "(profiles/r04_fetch_size_calibration.json for row gathers; profiles/r06_fetch_size_probe_calibration.json: a single-dword random "
                    "probe is ONE request = one 128-byte line)",
@@ -71,6 +73,7 @@ for p in sys.argv[3:]:
         algorithmic_bytes_per_launch=alg, fetched_over_algorithmic=round(total_fetch / alg, 3) if alg else None,
         work_per_step=None if not line else {k: line["roofline"][k] for k in ("searches_per_step", "hops_per_step", "dist_cmps_per_step")},
         per_kernel=per_kernel)
-    fn = os.path.join(REPO, "profiles", f"{tag}_mid_fraction_2pow{p}_pmc_traffic.json")
+    sfx = "" if not line or (line["config"]["beam"], line["config"]["final_beam_multiply"]) == (80, 1) else f"_beam{line['config']['beam']}x{line['config']['final_beam_multiply']}"
+    fn = os.path.join(REPO, "profiles", f"{tag}_fraction_2pow{p}{sfx}_pmc_traffic.json")
     json.dump(out, open(fn, "w"), indent=1)
     print(fn, "fetched/algorithmic", out["fetched_over_algorithmic"], "GB fetched", round(total_fetch / 1e9, 2))

@@ -41,7 +41,7 @@ struct Tuning {
   bool dense_always = false;   // WANN_DENSE_ALWAYS
   int heavy_ratio = 8;         // WANN_HEAVY_RATIO
   int spec_num = 8;            // WANN_SPEC_NUM
-  int spec_extra = 0;          // WANN_SPEC_EXTRA (see RouteArgs::spec_extra)
+  int spec_extra = 2;          // WANN_SPEC_EXTRA (see RouteArgs::spec_extra; 0: off)
   int npollers = 0;            // WANN_POLLERS (0: 32 with the scan, else 16)
   int deep_pollers = 0;        // WANN_DEEP_POLLERS (0: 4, or 16 where three workgroups share a CU)
   long long deep_min_tasks = 4096;  // WANN_DEEP_MIN_TASKS
@@ -123,7 +123,7 @@ struct Tuning {
     if (t.heavy_ratio < 1) t.heavy_ratio = 1;
     t.spec_num = num("WANN_SPEC_NUM", 8);
     if (t.spec_num < 1) t.spec_num = 1;
-    t.spec_extra = num("WANN_SPEC_EXTRA", 0);
+    t.spec_extra = num("WANN_SPEC_EXTRA", 2);
     t.npollers = num("WANN_POLLERS", 0);
     if (t.npollers < 0) t.npollers = 0;
     t.deep_pollers = num("WANN_DEEP_POLLERS", 0);

@@ -192,6 +192,11 @@ def main():
                sweep=rows, reference=[])
     if c["search_kernel_ms"] > 0:
         out["k_search_tb_per_s"] = round(out["algorithmic_gb_per_batch"] / c["search_kernel_ms"], 3)
+    if c.get("brute_rows", 0) > 0:
+        # fenwick / three_split: the end scans (k_brute) run BESIDE the graph searches (wann_host.cpp): the call's bytes are both
+        # kernels', its time is the device time of the call
+        out["scan_gb_per_batch"] = round(esz * d * c["brute_rows"] / 1e9, 3)
+        out["device_ms"] = round(c["device_ms"], 3)
     if args.config == "deep_l2":
         out["metric_note"] = "squared L2, as BASELINE.json configs[3]'s text states it; the reference's own deep runs are inner product (configs.deep)"
     if args.config == "deep":  # BASELINE.json's config text says "96-d L2"; the reference itself runs deep under inner product

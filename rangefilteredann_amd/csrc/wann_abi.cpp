@@ -489,13 +489,13 @@ int wann_predict_costs(wann_index *I, const float *ranges, int64_t nq, const cha
     ra.heavy_cap = W.big_stride;
     ra.mid_list = W.list_mid.p;
     ra.mid_count = W.ints.p + I_MID_COUNT;
-    ra.heavy_ratio = tune.heavy_ratio;
+    ra.heavy_ratio = kHeavyRatio;
     ra.risk_count = W.ints.p + I_RISK;
     ra.brute_list = W.list_brute.p;
     ra.brute_count = W.ints.p + I_BRUTE_COUNT;
     ra.spec = 0;  // (plain tasks only: each carries its window's size)
-    ra.spec_num = tune.spec_num;
-    ra.spec_extra = tune.spec_extra;
+    ra.spec_num = 8;
+    ra.spec_extra = kSpecExtraLevels;
     ra.cap_inkernel = (int32_t)std::max<int64_t>(kInKernelBeamCap, qp->beam_width);
     ra.sub_base0 = ra.sub_cap = (int32_t)(nq * maxt);
     ra.sub_count = W.ints.p + I_SUB_COUNT;

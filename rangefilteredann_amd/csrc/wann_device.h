@@ -169,7 +169,6 @@ struct SearchArgs {
   int32_t old_general;          // dev / test: the first-generation general core (wave_beam_search) instead
   int32_t cut_k;                // raw mode, unfiltered VamanaIndex queries: QueryParams::k and ::cut of beamSearch.h:159-167
   double cut;                   //   (0: no cut step -- the post-filter path never takes it)
-  int32_t search_prio;          // one-wave kernel: the search wave raises its issue priority (s_setprio 3)
   int32_t helper;               // one-wave kernel: number of helper waves per workgroup (0 or kHelpers) that prepare row + distance
                                 // packets ahead of the search (score_helper)
   unsigned long long *g_beam;   // per wave slot beam, g_beam_cap entries each (or null)
@@ -302,6 +301,8 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxLdsBits = 12;       // build kernels: seen-filters up to 2^12 entries live in the LDS
 constexpr int kSearchPoolBytes = 18432;  // k_search per-wave LDS pool: beam + filter of beams <= 128 (2^12 slots), beam alone <= 2304
 constexpr int kInKernelBeamCap = 1280;   // largest beam the first (in-kernel doubling) launch runs
+constexpr int kHeavyRatio = 8;           // a task whose partition is >= 8x its window is "heavy": served first, its levels speculated
+constexpr int kSpecExtraLevels = 2;      // RouteArgs::spec_extra (k_route: one more speculated level for short chains under wide windows)
 // one-wave kernel: helper waves per search wave (wann_wave.h score_helper) and the bytes of their LDS mailbox (ScoreBox,
 // at the end of the search wave's pool)
 constexpr int kHelpers = 3;

@@ -231,7 +231,6 @@ RoundCfg config_for(const wann_index &I, const Tuning &T, int64_t first_beam, in
   const int waves_per_cu = (I.view.metric == 1 || I.view.dtype != WANN_DTYPE_F32) ? 12 : 8;
   int blocks_per_cu = std::min((big_lds ? 8 : waves_per_cu) / wpb, lds_blocks_per_cu(per_block));
   blocks_per_cu = std::max(1, blocks_per_cu);
-  if (T.blocks_per_cu > 0) blocks_per_cu = std::max(1, std::min(blocks_per_cu, T.blocks_per_cu));  // dev knob
   int64_t blocks = (int64_t)I.num_cus * blocks_per_cu;
   const int cap_bits = hash_bits(cap);
   if (force_table || cap_bytes + ((int64_t)4 << cap_bits) > usable) {  // some beam of the range keeps its filter in global memory
@@ -261,7 +260,6 @@ int lean_pool_bytes(const wann_index &I, const Tuning &T) {
   // hipOccupancyMaxActiveBlocksPerMultiprocessor says (3): a launch of 768 such workgroups ran at the speed of 512 until round 4
   // measured it (stand-alone inner-product graph, 30 000 searches at beam 80: 6.65 ms at 53 KiB, 5.22 ms at 52.5 KiB and below).
   int pool = (52 * 1024) / kWavesPerBlock - common;
-  if (T.lean_pool > 0) pool = T.lean_pool;  // dev knob
   return pool >= kInKernelBeamCap * 8 + 1536 ? pool : 0;
 }
 
@@ -412,18 +410,18 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
   ra.graph_count = W.ints.p + I_GRAPH_COUNT;
   ra.heavy_list = W.list_heavy.p;
   ra.heavy_count = W.ints.p + I_HEAVY_COUNT;
-  ra.prio_count = T.evidence_first ? W.ints.p + I_PRIO_COUNT : nullptr;
+  ra.prio_count = W.ints.p + I_PRIO_COUNT;
   ra.heavy_cap = W.big_stride;
   ra.mid_list = W.list_mid.p;
   ra.mid_count = W.ints.p + I_MID_COUNT;
-  ra.heavy_ratio = T.heavy_ratio;
+  ra.heavy_ratio = kHeavyRatio;
   ra.risk_count = W.ints.p + I_RISK;
   ra.brute_list = W.list_brute.p;
   ra.brute_count = W.ints.p + I_BRUTE_COUNT;
   ra.spec = spec ? 1 : 0;
-  ra.spec_num = T.spec_num;
-  ra.spec_extra = T.spec_extra;
-  const int64_t inkernel_cap = T.inkernel_cap > 0 ? T.inkernel_cap : kInKernelBeamCap;
+  ra.spec_num = 8;
+  ra.spec_extra = kSpecExtraLevels;
+  const int64_t inkernel_cap = kInKernelBeamCap;
   ra.cap_inkernel = (int32_t)std::max<int64_t>(inkernel_cap, qp.beam_width);
   ra.sub_base0 = (int32_t)(nq * maxt);
   ra.sub_cap = (int32_t)(nq * maxt + sub_slots);
@@ -515,8 +513,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     }
     // (as many waves as the chip holds at once -- by the registers: two per SIMD for squared-L2 float rows (two 512-byte rows
     // per lane pair in flight), three for inner-product float rows, five for byte rows -- deal the tickets among themselves)
-    const int brute_per_cu = T.brute_per_cu > 0 ? T.brute_per_cu  // dev knob
-                             : (I.view.dtype != WANN_DTYPE_F32 ? 5 : (I.view.metric == 1 ? 3 : 2));
+    const int brute_per_cu = I.view.dtype != WANN_DTYPE_F32 ? 5 : (I.view.metric == 1 ? 3 : 2);
     int blocks = (int)std::min<int64_t>((int64_t)I.num_cus * brute_per_cu, (nq * std::min(maxt, 2) + kWavesPerBlock - 1) / kWavesPerBlock);
     if (launch_brute(ba, blocks, scan_st)) throw HipError(std::string("k_brute: ") + launch_last_error());
     if (scans_aside) HIP_CHECK(hipEventRecord(W.ev_scan, scan_st));
@@ -553,7 +550,6 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
       sa.vlog_n = W.vlog_n.p;
       sa.vlog_cap = kVlogCap;
     }
-    sa.search_prio = T.search_prio;  // dev knob
     sa.out_key = W.out_key.p;
     sa.out_cnt = W.out_cnt.p;
     sa.ctr = W.ctr.p;
@@ -577,8 +573,8 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     for (const PartDesc &pd : I.parts) max_part = std::max<int64_t>(max_part, pd.n);
     const int64_t seen_words = ((max_part + 127) / 128) * 4;
     sa.old_general = (T.old_general || I.view.rs > 64 || verbose_call) ? 1 : 0;
-    // (idle pollers look for chains that will outgrow their speculated levels: on unless WANN_SCAN=0)
-    const bool scan_on = spec && T.scan && T.lookahead;
+    // (idle pollers look for chains that will outgrow their speculated levels)
+    const bool scan_on = spec && T.lookahead;
     auto launch = [&](SearchArgs &a, int64_t first_beam, int64_t cap, int64_t items, bool big_lds, int32_t with_big_cap = 0, int32_t deep_pollers = 0,
                       int base_pool = kSearchPoolBytes) {
       RoundCfg rc = config_for(I, T, first_beam, cap, items, big_lds || verbose_call, a.force_general != 0, a.old_general != 0, base_pool);
@@ -612,7 +608,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         big.pool_bytes = (common + kSearchPoolBytes) * kWavesPerBlock - common;
         // A companion workgroup of this size shares its CU with an ordinary one (80 KB of LDS and <= 256 registers each).
         // The few pollers of a launch without big items (deep chains) are worth a CU each: they book its whole LDS.
-        if (T.big_exclusive >= 0 ? T.big_exclusive != 0 : deep_pollers > 0) big.pool_bytes = 150 * 1024 - common;
+        if (deep_pollers > 0) big.pool_bytes = 150 * 1024 - common;
         big.big_list = W.list_big.p;
         big.big_count = W.ints.p + I_BIG_COUNT;
         big.big_stride = W.big_stride;
@@ -626,15 +622,15 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         big.g_epoch = W.g_epoch_big.p;
         big.g_seen = W.g_seen_big.p;
         big.g_seen_words = seen_words;
-        a.yield_for_big = T.yield ? 1 : 0;
+        a.yield_for_big = 1;
         a.big_resident = big.big_resident = W.ints.p + I_BIG_RESIDENT;
         a.big_count = W.ints.p + I_BIG_COUNT;
         if (use_pollers) {
           // (companion workgroups share their CUs: pollers are cheap; with the scan on, idle ones look for chains that need a look-ahead)
-          a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : (T.npollers > 0 ? T.npollers : (scan_on ? 32 : 16));
-          // (the first npollers companion workgroups never touch the static list: with WANN_POLLERS >= the launch's workgroups
+          a.npollers = big.npollers = deep_pollers > 0 ? deep_pollers : (scan_on ? 32 : 16);
+          // (the first npollers companion workgroups never touch the static list: with as many pollers as the launch has workgroups
           // nobody would search the speculated levels, and the tasks would resolve without them -- wrong rows, measured with
-          // WANN_POLLERS=256.  At least half of the workgroups always serve the list; they join the pollers when it is done.)
+          // 256 pollers.  At least half of the workgroups always serve the list; they join the pollers when it is done.)
           a.npollers = big.npollers = std::min<int32_t>(a.npollers, std::max(1, I.num_cus / 2));
           if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
           if (spec && T.lookahead) {  // look-ahead searches for chains that keep failing (k_search)
@@ -646,8 +642,8 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
             if (deep_pollers == 0 && scan_on) {  // (companion mode: there are speculating tasks)
               big.scan_list = W.list_big.p + 3 * (size_t)W.big_stride;
               big.scan_count = W.ints.p + I_SCAN_COUNT;
-              big.scan_min_top = T.scan_min_top;
-              big.scan_num = T.scan_num;
+              big.scan_min_top = 2560;
+              big.scan_num = 16;
             }
             if (T.la_eager) {  // test hook: every chain that fails its second level asks for one
               a.la_min_beam = big.la_min_beam = (int32_t)(2 * first_beam);
@@ -708,7 +704,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         // the two hardware queues reaches the CUs first differed from call to call: on the SIFT-1M 2^-3 batch every second
         // call handed 0 - 3 of its 4 third-level chains over instead of 4 and took 3.19 instead of 2.76 ms.  A one-thread
         // kernel holds this stream until the pollers have started.
-        if (deep_pollers > 0 && T.gate)
+        if (deep_pollers > 0)
           if (launch_gate(W.ints.p + I_BIG_RESIDENT, big.npollers, st)) throw HipError(std::string("k_gate: ") + launch_last_error());
       }
       if (launch_search(a, rc.lc, st)) throw HipError(std::string("k_search: ") + launch_last_error());
@@ -738,7 +734,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     sa.heavy_count = W.ints.p + I_HEAVY_COUNT;
     // longest searches first (k_order_heavy) where a launch has levels of several milliseconds: those in the companion launch
     // tell (2^-7 ... 2^-9 of SIFT-1M: 1 ms less per batch; at the wide windows the order of query numbers is as good)
-    if (big_n > 0 && W.h_ints[I_HEAVY_COUNT] >= 256 && T.order) {
+    if (big_n > 0 && W.h_ints[I_HEAVY_COUNT] >= 256) {
       OrderArgs oa{W.tasks.p, W.list_heavy.p, W.list_heavy_ordered.p, W.ints.p + I_HEAVY_COUNT};
       if (launch_order_heavy(oa, st)) throw HipError(std::string("k_order_heavy: ") + launch_last_error());
       sa.heavy_list = W.list_heavy_ordered.p;
@@ -762,13 +758,13 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
     // Three workgroups per CU (a leaner LDS pool) where the kernel allows it and no companion workgroup has to share a CU with
     // the ordinary ones (the deep-chain pollers book whole CUs of their own)
     int base_pool = kSearchPoolBytes;
-    if (big_n == 0 && !may_continue && T.lean && cap1 <= kInKernelBeamCap && lean_pool_bytes(I, T) > 0) base_pool = lean_pool_bytes(I, T);
+    if (big_n == 0 && !may_continue && cap1 <= kInKernelBeamCap && lean_pool_bytes(I, T) > 0) base_pool = lean_pool_bytes(I, T);
     // How many: with two workgroups per CU (squared-L2 float kernel) four -- 16 cost the SIFT-1M 2^-3 batch 2.5 %; with three
     // (twelve waves share a CU's memory path: a third level takes 2.2 ms there, 1.5 ms on a poller) every third-level chain
     // should find one: 16 (deep-10M-like, eight such chains: 5.3 -> 4.5 ms per batch; 12 ... 32 measure alike).
     if (big_n == 0 && !may_continue && use_pollers && big_cap > 0 && graph_n >= deep_min && graph_n * b0 >= deep_min * 150 &&
-        T.deep && std::max<int64_t>(4 * b0, 256) <= cap1)
-      deep = T.deep_pollers > 0 ? T.deep_pollers : (base_pool != kSearchPoolBytes ? 16 : 4);
+        std::max<int64_t>(4 * b0, 256) <= cap1)
+      deep = base_pool != kSearchPoolBytes ? 16 : 4;
     launch(sa, b0, cap1, graph_n, false, (big_n > 0 || may_continue || deep > 0) ? big_cap : 0, deep, base_pool);
     HIP_CHECK(hipMemcpyAsync(W.h_ints, W.ints.p, kInts * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

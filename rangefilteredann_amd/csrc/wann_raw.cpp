@@ -94,8 +94,7 @@ struct RawGraph {
     const bool wide = I.view.rs > 64;
     const bool old_general = T.old_general || with_cut || wide, force_general = T.force_general || with_cut || wide;
     // (dev / test switches: the large-LDS one-wave configuration; the first-generation cores live in that kernel only)
-    // (dev: WANN_LEAN_POOL under WANN_TEST_HOOKS=1 gives the raw search the leaner per-wave pool too -- three workgroups per CU)
-    const int raw_pool = (T.hooks_live && T.lean_pool > 0) ? T.lean_pool : kSearchPoolBytes;
+    const int raw_pool = kSearchPoolBytes;
     RoundCfg rc = config_for(I, T, beam, beam, nq, T.raw_big_lds || old_general, force_general, old_general, raw_pool);
     SearchArgs sa{};
     sa.ix = I.view;

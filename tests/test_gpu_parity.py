@@ -647,7 +647,7 @@ def _continuation_case(wa):
     return idx, Q, labels, nq
 
 
-@pytest.mark.parametrize("variant", ["default", "WANN_SCAN=0", "WANN_LA_EAGER", "WANN_NO_ORDER"])
+@pytest.mark.parametrize("variant", ["default", "WANN_LA_EAGER", "WANN_NO_LOOKAHEAD"])
 def test_mid_fraction_machinery_matches_oracle(oracle, wa, gpu, tmp_path, monkeypatch, variant):
     """The scheduling machinery of the mid window fractions -- speculative levels, the companion launch of the one-wave kernel
     (search wave + scoring helper waves), pollers, look-aheads, deep hand-offs -- against the ORACLE (not against itself) at
@@ -658,12 +658,10 @@ def test_mid_fraction_machinery_matches_oracle(oracle, wa, gpu, tmp_path, monkey
     X, Q = g(n), g(nq)
     labels = distinct_labels(n, 16)
     cache = str(tmp_path) + "/"
-    if variant == "WANN_SCAN=0":
-        monkeypatch.setenv("WANN_SCAN", "0")
+    if variant == "WANN_NO_LOOKAHEAD":  # (no look-ahead searches and no scan of the idle pollers)
+        monkeypatch.setenv("WANN_NO_LOOKAHEAD", "1")
     if variant == "WANN_LA_EAGER":  # (every chain that fails its second level asks for a look-ahead)
         monkeypatch.setenv("WANN_LA_EAGER", "1")
-    if variant == "WANN_NO_ORDER":  # (the heavy list in query order instead of longest first: k_order_heavy off)
-        monkeypatch.setenv("WANN_NO_ORDER", "1")
     monkeypatch.setenv("WANN_DEEP_MIN_TASKS", "1")  # (800 tasks would not count as a saturated launch)
     idx = wa.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=wa.BuildParams(24, 64, 1.0, cache))
     ref = oracle.VamanaRangeFilterTreeIndexFloatEuclidian(X, labels, cutoff=1000, split_factor=2, build_params=oracle.BuildParams(24, 64, 1.0, cache))
@@ -719,11 +717,11 @@ def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
     handed = stranded = 0
     for p, beam, mult in [(-3, 64, 1), (-4, 64, 2), (-2, 100, 1)]:
         W = windows(labels, nq, p, seed=9)
-        monkeypatch.setenv("WANN_NO_DEEP", "1")
+        monkeypatch.setenv("WANN_DEEP_MIN_TASKS", str(10**9))  # (no launch of this test counts as saturated: no deep-chain pollers)
         ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
         c = idx.counters()
         assert c["deep_handoffs"] == 0
-        monkeypatch.delenv("WANN_NO_DEEP")
+        monkeypatch.delenv("WANN_DEEP_MIN_TASKS")
         monkeypatch.setenv("WANN_DEEP_MIN_TASKS", "1")
         ids2, dists2 = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
         c2 = idx.counters()

@@ -11,7 +11,7 @@ SRC = r'''
 int main() {
   wann::Tuning t = wann::Tuning::from_env();
   wann::Tuning u = wann::Tuning::from_env();
-  printf("%d %d %d %d %d %d %.1f\n", (int)t.hooks_live, (int)t.spec, (int)t.gemm, t.spec_num, (int)t.force_general, (int)t.verbose, t.proof_factor);
+  printf("%d %d %d %d %d %d %.1f\n", (int)t.hooks_live, (int)t.spec, (int)t.gemm, (int)t.deep_min_tasks, (int)t.force_general, (int)t.verbose, t.proof_factor);
   return (t.spec == u.spec) ? 0 : 1;
 }
 '''
@@ -30,14 +30,14 @@ def _run(tmp_path, env_extra):
 
 
 def test_lab_switches_need_the_hooks(tmp_path):
-    lab = {"WANN_NO_SPEC": "1", "WANN_NO_GEMM": "1", "WANN_SPEC_NUM": "12", "WANN_FORCE_GENERAL": "1", "WANN_VERBOSE": "1", "WANN_PROOF_FACTOR": "5"}
+    lab = {"WANN_NO_SPEC": "1", "WANN_NO_GEMM": "1", "WANN_DEEP_MIN_TASKS": "12", "WANN_FORCE_GENERAL": "1", "WANN_VERBOSE": "1", "WANN_PROOF_FACTOR": "5"}
     out, err = _run(tmp_path, lab)
-    assert out == ["0", "1", "1", "8", "0", "1", "5.0"]  # defaults, except the two production names
+    assert out == ["0", "1", "1", "4096", "0", "1", "5.0"]  # defaults, except the two production names
     assert err.count("IGNORED without WANN_TEST_HOOKS=1") == 1  # (two records were made: named once)
-    for name in ("WANN_NO_SPEC", "WANN_NO_GEMM", "WANN_SPEC_NUM", "WANN_FORCE_GENERAL"):
+    for name in ("WANN_NO_SPEC", "WANN_NO_GEMM", "WANN_DEEP_MIN_TASKS", "WANN_FORCE_GENERAL"):
         assert name in err
     assert "WANN_VERBOSE" not in err and "WANN_PROOF_FACTOR" not in err
     out, err = _run(tmp_path, dict(lab, WANN_TEST_HOOKS="1"))
     assert out == ["1", "0", "0", "12", "1", "1", "5.0"] and err == ""
     out, err = _run(tmp_path, {})
-    assert out == ["0", "1", "1", "8", "0", "0", "3.0"] and err == ""
+    assert out == ["0", "1", "1", "4096", "0", "0", "3.0"] and err == ""

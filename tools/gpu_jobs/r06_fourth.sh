@@ -1,4 +1,5 @@
 #!/bin/bash
+# (WANN_SPEC_EXTRA was a laboratory knob of this commit: profiles/r06_extra_level_speculation.txt; the gated rule is a constant now, kSpecExtraLevels)
 # round 6, fourth GPU call: one more speculated level for long chains (WANN_SPEC_EXTRA) per window fraction, its parity under the
 # mid-fraction tests, the fenwick / three_split legs with the scans beside the searches, FETCH_SIZE of the new driver-line legs,
 # bench.py under the launcher with one rank against the plain N = 1 run

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (WANN_INKERNEL_CAP was a laboratory knob of this commit; the result is profiles/r06_inkernel_cap_sweep.txt and the knob is gone)
 # round 6, second GPU call: (1) the tie-heavy parity test against the round-5 core (it must FAIL there), (2) the four-wave kernel's
 # beam cap lowered (WANN_INKERNEL_CAP: levels above it run in the one-wave kernel with its helper waves), full counters per fraction,
 # (3) the new multi-rank / production-mode tests, (4) the uint8 leg of the driver line

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (WANN_INKERNEL_CAP: see r06_second.sh)
 # round 6, third GPU call: what ends a mid-fraction batch NOW -- per-search timelines (TRACE build) at 2^-5 / 2^-6 / 2^-7 / 2^-9 with the
 # default cap and with the four-wave kernel's cap lowered, phase cycles of the one-wave core alone and inside a 2^-9 batch (PROFILE build),
 # the fixed multi-rank worker, FETCH_SIZE of every window fraction

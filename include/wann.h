@@ -234,8 +234,9 @@ int wann_raw_beam_search(int metric, const float *points, int64_t n, int64_t d,
  * index opened from a point file (uint32 n, uint32 d, n*d elements of dtype: point_range.h:63-93) and a graph file
  * (graph.h:126-196: the format of the graph cache).  batch_search = beam_search from node 0 with
  * QueryParams(knn, beam_width, 1.35, n, max_degree) -- including the k / cut step of beamSearch.h:159-167, which only this
- * path takes -- and the first knn entries of the final beam (a shorter beam is padded with id 2^32-1, FLT_MAX; the reference
- * reads past it).  queries: host (nq,d) of the index's dtype. */
+ * path takes (it lives in the first-generation core of the one-wave legacy kernel, k_search<., 2>: same rows as the reference, a
+ * fraction of the filtered path's throughput) -- and the first knn entries of the final beam (a shorter beam is padded with id
+ * 2^32-1, FLT_MAX; the reference reads past it).  queries: host (nq,d) of the index's dtype. */
 typedef struct wann_vamana wann_vamana;
 wann_vamana *wann_vamana_open(int metric, int dtype, const char *data_path, const char *graph_path, int device);
 void wann_vamana_close(wann_vamana *index);

@@ -170,11 +170,14 @@ void upload_index(wann_index &I) {
 // Global scratch of a launch whose searches keep their seen-filter in global memory: the per-slot filter tables
 // (entries tagged with the slot's search epoch), the epochs, and the per-slot exact seen bitmaps.  A table whose
 // slot layout changes (or that was reallocated) is zeroed together with its epochs.
-void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBuf<uint32_t> &seen, int64_t &layout, int slots,
-                           int table_bits, int64_t seen_words, hipStream_t st, bool any_slots) {
+int ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBuf<uint32_t> &seen, int64_t &layout, int slots,
+                          int table_bits, int64_t seen_words, hipStream_t st, bool any_slots) {
+  // any_slots: a slot's region depends on the region stride only (slot << stride bits), so launches with different slot counts
+  // share one zeroed table -- and the stride never SHRINKS: a launch whose filters are smaller than the largest seen so
+  // far uses a prefix of every region (the search masks with its own `bits`), instead of a 2^bits-word re-layout that zeroes the
+  // whole table and every epoch each time two launch shapes alternate.  The stride in use is returned (SearchArgs::g_table_bits).
+  if (any_slots && layout > table_bits && layout < 32 && ((size_t)slots << layout) * sizeof(int32_t) <= ((size_t)20 << 30)) table_bits = (int)layout;
   const size_t need = (size_t)slots << table_bits;
-  // any_slots: a slot's region depends on the table size only (slot << table_bits), so launches with different slot counts
-  // share one zeroed table
   const int64_t want = any_slots ? (int64_t)table_bits : (((int64_t)slots << 8) | table_bits);
   const bool fresh = need > table.cap || (size_t)slots > epoch.cap;
   table.ensure(need);
@@ -185,6 +188,7 @@ void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBu
     HIP_CHECK(hipMemsetAsync(epoch.p, 0, epoch.cap * sizeof(int32_t), st));
     layout = want;
   }
+  return table_bits;
 }
 
 // Launch geometry for a k_search launch whose searches run beams in [first_beam, cap].
@@ -673,7 +677,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         } else if (rc.lc.big == 0) {  // four-wave kernel (third-generation general core): tagged filter entries, no seen bitmaps
           // (the slot count of this launch follows the batch size: the layout key is the table size alone, and the buffers
           // only ever grow -- a fresh allocation is zeroed whole)
-          ensure_filter_scratch(W.g_table, W.g_epoch, W.g_seen, W.g_table_layout, rc.slots, rc.table_bits, 0, st, /*any_slots=*/true);
+          rc.table_bits = ensure_filter_scratch(W.g_table, W.g_epoch, W.g_seen, W.g_table_layout, rc.slots, rc.table_bits, 0, st, /*any_slots=*/true);
           a.g_table = W.g_table.p;
           a.g_epoch = W.g_epoch.p;
         } else {  // legacy one-wave kernel (first-generation general cores): a plain per-slot table, cleared per search

@@ -181,8 +181,8 @@ namespace wann_host {
 
 Tuning snapshot_tuning(wann_index &I);  // the index's switches for one call (WANN_TEST_HOOKS=1: re-read from the environment first)
 void upload_index(wann_index &I);
-void ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBuf<uint32_t> &seen, int64_t &layout, int slots,
-                           int table_bits, int64_t seen_words, hipStream_t st, bool any_slots = false);
+int ensure_filter_scratch(DevBuf<int32_t> &table, DevBuf<int32_t> &epoch, DevBuf<uint32_t> &seen, int64_t &layout, int slots,
+                          int table_bits, int64_t seen_words, hipStream_t st, bool any_slots = false);
 struct RoundCfg {
   LaunchCfg lc;
   bool big_lds;      // the one-wave-per-workgroup kernel

@@ -715,7 +715,9 @@ def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
     over chains that reach their third level; which wave runs a search must not change a row or a work counter."""
     idx, Q, labels, nq = _continuation_case(wa)
     handed = stranded = 0
-    for p, beam, mult in [(-3, 64, 1), (-4, 64, 2), (-2, 100, 1)]:
+    # (2^-5 / 2^-6 at beam 64: windows too narrow for the extra speculated level of short chains -- k_route, round 6 -- so their
+    # third levels are sequential continuations, which is what gets handed over)
+    for p, beam, mult in [(-3, 64, 1), (-5, 64, 1), (-4, 64, 2), (-6, 64, 2), (-2, 100, 1)]:
         W = windows(labels, nq, p, seed=9)
         monkeypatch.setenv("WANN_DEEP_MIN_TASKS", str(10**9))  # (no launch of this test counts as saturated: no deep-chain pollers)
         ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))

@@ -3,11 +3,11 @@
 export TMPDIR=/tmp
 O=gpurun_out/r06val
 mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 -rs > $O/gpu_tests.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 -rs ${PYTEST_SELECT:-} > $O/gpu_tests.log 2>&1
 tail -22 $O/gpu_tests.log | cut -c1-200
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-/usr/bin/time -v python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.log
-grep "Elapsed (wall" $O/bench_n1.log
+SECONDS=0; python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.log; echo "bench.py wall: $SECONDS s"
+
 python3 - <<'PY'
 import json
 d = json.loads([l for l in open("gpurun_out/r06val/bench_n1.json") if l.startswith("{")][-1])

@@ -718,6 +718,8 @@ def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
     # (2^-5 / 2^-6 at beam 64: windows too narrow for the extra speculated level of short chains -- k_route, round 6 -- so their
     # third levels are sequential continuations, which is what gets handed over)
     for p, beam, mult in [(-3, 64, 1), (-5, 64, 1), (-4, 64, 2), (-6, 64, 2), (-2, 100, 1)]:
+        narrow = p <= -5  # (such a batch may also have chains that double beyond the in-kernel cap: companion mode, whose unserved
+        #                    continuations the host recovers -- test_unserved_continuations_are_recovered)
         W = windows(labels, nq, p, seed=9)
         monkeypatch.setenv("WANN_DEEP_MIN_TASKS", str(10**9))  # (no launch of this test counts as saturated: no deep-chain pollers)
         ids, dists = idx.batch_search(Q, W, nq, "optimized_postfilter", _qp(wa, beam, mult))
@@ -743,7 +745,7 @@ def test_deep_chains_go_to_idle_pollers(wa, gpu, monkeypatch):
         assert np.array_equal(ids, ids3) and np.array_equal(dists, dists3), (p, beam, mult)
         assert (c["beam_searches"], c["hops"], c["dist_cmps"]) == (c3["beam_searches"], c3["hops"], c3["dist_cmps"]), (c, c3)
         # nothing is handed to pollers that are not there: no hand-off, no look-ahead, nothing for the host to recover
-        assert c3["deep_handoffs"] == 0 and c3["lookaheads_issued"] == 0 and c3["recovered_continuations"] == 0, c3
+        assert c3["deep_handoffs"] == 0 and c3["lookaheads_issued"] == 0 and (narrow or c3["recovered_continuations"] == 0), c3
         stranded += c3["recovered_continuations"]
     assert handed > 0, "no chain of this test reached its third level next to an idle poller"
 

@@ -999,8 +999,7 @@ struct ScoreBox {     // LDS mailbox; head written by the search wave, packet sl
   int32_t bits;       // its filter size (log2)
   int32_t qid_lo, qid_hi;  // the query's own id (never scored, beamSearch.h:128)
   int32_t last_gen;   // the last generation used (generations never repeat within a launch)
-  int32_t wb_off;     // the running search's bitmap of written filter-slot groups: byte offset from the workgroup's LDS base (wb_words = 0: none)
-  int32_t wb_words, wb_shift;  // its size in 32-bit words; a bit covers 2^wb_shift slots
+  int32_t pad0;
   int32_t req[kReqRing];                // request i: the node, at i % kReqRing
   unsigned long long tag[kPkSlots];     // (generation << 32 | node) of a complete packet; 0 while a helper rewrites the slot
   unsigned long long mask[kPkSlots];    // lanes of the row whose distance the packet holds
@@ -1025,8 +1024,6 @@ __device__ __forceinline__ void score_helper(const IndexView &ix, int32_t *gtabl
   const int lane = lane_id();
   LdsBox *vb = lds_box(box);
   int my_gen = 0, next = hidx, bits = 10;
-  const uint32_t *wbits = nullptr;  // (LDS; the search wave sets bits, this wave only reads them: a stale bit costs the touch, nothing else)
-  int wshift = 0;
   int64_t row_base = 0, row_off = 0, qid = -1;
   uint32_t tmask = 0;
   for (;;) {
@@ -1046,8 +1043,6 @@ __device__ __forceinline__ void score_helper(const IndexView &ix, int32_t *gtabl
       bits = vb->bits;
       tmask = (1u << bits) - 1u;
       qid = ((int64_t)vb->qid_hi << 32) | (uint32_t)vb->qid_lo;
-      wbits = vb->wb_words > 0 ? reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(qv) + vb->wb_off) : nullptr;
-      wshift = vb->wb_shift;
     }
     const int head = vb->req_head;
     while (head - next > kReqRing - 4) next += kHelpers;  // far behind: those ring entries are gone, nobody waits for them
@@ -1070,12 +1065,7 @@ __device__ __forceinline__ void score_helper(const IndexView &ix, int32_t *gtabl
     uint32_t w = ~0u;
     int touch = 0;
     if (valid) {
-      bool written = true;
-      if (wbits) {
-        const uint32_t g = loc >> wshift;
-        written = (wbits[g >> 5] >> (g & 31u)) & 1u;
-      }
-      if (written) touch = gtable[loc];  // the search wave's filter probe will hit the L2 (slots this search has not written are not probed)
+      touch = gtable[loc];  // the search wave's filter probe will hit the L2
       w = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, kSeenScope);
     }
     // do two valid lanes of the row share a filter slot?  (exact, by `bits` ballots: this wave is not on the critical path)
@@ -1174,12 +1164,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
                                                      long long &ncmp_out, unsigned long long *prof = nullptr,
                                                      ScoreBox *box = nullptr, int part_index = 0,
                                                      const int32_t *abort_flag = nullptr, Counters *ctr = nullptr,
-                                                     const long long *moot_word = nullptr, int my_level = 0,
-                                                     uint32_t *wbits = nullptr, int wwords = 0, int wshift = 0, int wb_off = 0) {
-  // wbits (LDS, wwords 32-bit words, or null): one bit per 2^wshift filter slots -- "a slot of this group has been written by this
-  // search".  A neighbour whose bit is clear finds an entry of an older epoch (or none) whatever the table holds: its probe is not
-  // issued (old = -1, never equal to a tagged id), and the helper waves do not touch its line either.  wb_off: the bitmap's byte
-  // offset from the workgroup's LDS base, for the helper waves.
+                                                     const long long *moot_word = nullptr, int my_level = 0) {
   // abort_flag: a look-ahead search (k_search) that its chain has withdrawn (*abort_flag == 2) stops at the next check
   // moot_word: a speculated level stops when a LOWER level of its task has found k entries (*moot_word < my_level)
   //
@@ -1203,7 +1188,6 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   degree_limit = uni(degree_limit);
   mini_mask = (uint32_t)uni((int)mini_mask);
   part_index = uni(part_index);
-  wshift = uni(wshift);
   const int lane = lane_id();
   const uint32_t tmask = (1u << bits) - 1u;
   const int64_t row_off = uni(part.start);
@@ -1212,27 +1196,10 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
   u64 *const mb = L.lbeam;
   LdsBox *const vb = lds_box(box);
   int my_gen = 0, st_pk = 0, st_own = 0, st_nx = 0;
-  if (wbits)
-    for (int i = lane; i < wwords; i += 64) wbits[i] = 0u;
-  // has this search written a slot of the group of `loc`?  (no bitmap: assume so)
-  auto group_written = [&](uint32_t loc) -> bool {
-    if (!wbits) return true;
-    const uint32_t g = loc >> wshift;
-    return (wbits[g >> 5] >> (g & 31u)) & 1u;
-  };
-  auto mark_written = [&](bool stores, uint32_t loc) {
-    if (wbits && stores) {
-      const uint32_t g = loc >> wshift;
-      __hip_atomic_fetch_or(wbits + (g >> 5), 1u << (g & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  };
   if (box) {  // a new search for the helper waves (the query is staged already)
     if (lane == 0) {
       vb->part = part_index;
       vb->bits = bits;
-      vb->wb_off = wb_off;
-      vb->wb_words = wbits ? wwords : 0;
-      vb->wb_shift = wshift;
       vb->qid_lo = (int32_t)(uint32_t)qid;
       vb->qid_hi = (int32_t)(qid >> 32);
       vb->req_head = 0;
@@ -1444,10 +1411,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
         nx_node = nn;
         // (no lane-dependent branch around the loads: an unused slot's filter slot lies inside the table like any other,
         // and its seen-set word is read at node 0)
-        // (slots whose group this search has not written hold nothing of it: no probe -- a 4-byte read of a table of up to 32 MiB
-        // is a 128-byte fabric request; -1 is never equal to a tagged id)
-        nx_old = -1;
-        if (group_written(nx_loc & tmask)) nx_old = gtable[nx_loc & tmask];
+        nx_old = gtable[nx_loc & tmask];
         nx_sw = __hip_atomic_load(gseen + ((nx_a < 0 ? 0 : nx_a) >> 5), __ATOMIC_RELAXED, kSeenScope);
       }
     }
@@ -1532,7 +1496,6 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       const bool take = kept && !((sw >> (a & 31)) & 1u);  // what is computed
       asm volatile("" ::"v"(sw), "v"(old));
       if (kept) gtable[loc] = tagged;  // (a slot that holds the id already is left alone: its line -- of a table of up to 32 MiB -- stays clean)
-      mark_written(kept, loc);
       if (take) __hip_atomic_fetch_or(gseen + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, kSeenScope);
       WANN_PHASE(4);
       fetch_next();
@@ -1644,7 +1607,7 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       }
       valid = (a >= 0) && (lane < degree_limit) && ((int64_t)a != qid);
       if (valid) {
-        if (group_written(loc)) old = gtable[loc];
+        old = gtable[loc];
         sw = __hip_atomic_load(gseen + (a >> 5), __ATOMIC_RELAXED, kSeenScope);
       }
     }
@@ -1694,7 +1657,6 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
     if (WANN_LIKELY(!clash)) {
       seen = valid && (old == tagged);
       if (valid && !seen) gtable[loc] = tagged;
-      mark_written(valid && !seen, loc);
     } else {  // exact emulation of the sequential rule (as in wave_beam_search)
       u64 eq = ballot64(valid);
       for (int b = 0; b < bits; b++) {
@@ -1709,7 +1671,6 @@ __device__ __forceinline__ void wave_beam_search_big(const IndexView &ix, const 
       seen = valid && (lower ? (prev_val == a) : (old == tagged));
       WAVE_SYNC();
       if (valid && higher == 0) gtable[loc] = tagged;
-      mark_written(valid && higher == 0, loc);
       // does the row list one node twice (the reference's builder can append the start point twice)?
       u64 lm = lower;
       while (ballot64(lm != 0)) {

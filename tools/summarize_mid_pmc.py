@@ -26,7 +26,9 @@ def timed(vals):  # the timed launches: warm-up / ground-truth batches of other 
     return statistics.median(v), len(v)
 
 
-for p in sys.argv[3:]:
+for ptok in sys.argv[3:]:  # '-9' (directories pmc-9_g*) or '-8_40,1' (directories pmc-8_40,1_g*)
+    p = ptok
+    frac = int(ptok.split('_')[0])
     line = None
     for g in range(1, 9):
         fn = os.path.join(src, f"pmc{p}_g{g}.json")
@@ -59,11 +61,11 @@ for p in sys.argv[3:]:
         per_kernel[kind] = rec
     alg = line["roofline"]["algorithmic_bytes_per_step"] if line else None  # (graph rows + scored vectors + labels; exact scans are not in it)
     out = dict(
-        what=f"SIFT-1M-like 2-WST, window fraction 2^{p}, 10 000 queries, the setting named below: rocprofv3 --pmc passes (one counter group per run) of "
+        what=f"SIFT-1M-like 2-WST, window fraction 2^{frac}, 10 000 queries, the setting named below: rocprofv3 --pmc passes (one counter group per run) of "
              "bench.py --fractions headline --fraction p --setting beam,mult --pipeline 0.  Under --pmc the runtime serialises dispatches: the companion launch "
              "(k_search<0, 1>) runs BEFORE the ordinary one instead of beside it, its pollers give up, and continuations / look-aheads run in "
              "follow-up launches -- the bytes are those of the batch, the kernels' durations are not the concurrent batch's",
-        kernel=" + ".join(sorted(per_kernel)) + " (sum per batch)", n=1_000_000, nq=10_000, fraction=int(p),
+        kernel=" + ".join(sorted(per_kernel)) + " (sum per batch)", n=1_000_000, nq=10_000, fraction=frac,
         beam=line["config"]["beam"] if line else 80, mult=line["config"]["final_beam_multiply"] if line else 1,
         scan_only=bool(line and line["roofline"]["hops_per_step"] == 0),  # (every window takes the exact scan: the setting changes nothing)
         correction="FETCH_SIZE (KiB) x 1024 x 2: TCC_EA0_RDREQ_32B is 0 in every pass, i.e. every request is a full line; bytes = RDREQ x 128 B "
@@ -74,6 +76,6 @@ for p in sys.argv[3:]:
         work_per_step=None if not line else {k: line["roofline"][k] for k in ("searches_per_step", "hops_per_step", "dist_cmps_per_step")},
         per_kernel=per_kernel)
     sfx = "" if not line or (line["config"]["beam"], line["config"]["final_beam_multiply"]) == (80, 1) else f"_beam{line['config']['beam']}x{line['config']['final_beam_multiply']}"
-    fn = os.path.join(REPO, "profiles", f"{tag}_fraction_2pow{p}{sfx}_pmc_traffic.json")
+    fn = os.path.join(REPO, "profiles", f"{tag}_fraction_2pow{frac}{sfx}_pmc_traffic.json")
     json.dump(out, open(fn, "w"), indent=1)
     print(fn, "fetched/algorithmic", out["fetched_over_algorithmic"], "GB fetched", round(total_fetch / 1e9, 2))

@@ -637,9 +637,7 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
           // 256 pollers.  At least half of the workgroups always serve the list; they join the pollers when it is done.)
           a.npollers = big.npollers = std::min<int32_t>(a.npollers, std::max(1, I.num_cus / 2));
           if (deep_pollers > 0) a.handoff_beam = (int32_t)std::max<int64_t>(4 * first_beam, 256);
-#if defined(WANN_AB) && (WANN_AB == 7 || WANN_AB == 8)
-          else a.handoff_beam = WANN_AB == 7 ? 640 : 1280;  // dev A/B: in-cap continuations of a companion-mode launch move to idle pollers too
-#endif
+          // (companion mode hands no in-cap continuation over: measured, profiles/r06_companion_mode_handoff_experiment.txt -- they queue on the pollers)
           if (spec && T.lookahead) {  // look-ahead searches for chains that keep failing (k_search)
             a.la_count = big.la_count = W.ints.p + I_SUB_COUNT;
             a.la_base0 = big.la_base0 = (int32_t)(nq * maxt);

@@ -59,8 +59,36 @@ struct Tuning {
         "WANN_PROFILE_PHASES", "WANN_TASK_TRACE", nullptr};
     return names;
   }
+  // every WANN_* name this library or its Python package reads (beside the laboratory): anything else in the environment is a
+  // typo or a switch of another version -- named once on stderr (a sweep over a variable nothing reads ran silently)
+  static bool known_name(const char *name, size_t len) {
+    static const char *const names[] = {"WANN_TEST_HOOKS", "WANN_VERBOSE", "WANN_PROOF_FACTOR", "WANN_DEVICES", "WANN_DEVICE", "WANN_ASYNC_LANES",
+                                        "WANN_HOST_BUILD", "WANN_REF_TIES", "WANN_BUILD_VIS_CAP", "WANN_NO_TORCH", "WANN_DATASET_FOLDER", "WANN_LIB", nullptr};
+    static const char *const prefixes[] = {"WANN_BENCH_", "WANN_PF_", "WANN_FULLSIZE_", nullptr};  // (bench.py / tools / tests)
+    for (const char *const *n = names; *n; n++)
+      if (strlen(*n) == len && !strncmp(*n, name, len)) return true;
+    for (const char *const *n = lab_names(); *n; n++)
+      if (strlen(*n) == len && !strncmp(*n, name, len)) return true;
+    for (const char *const *n = prefixes; *n; n++)
+      if (len >= strlen(*n) && !strncmp(*n, name, strlen(*n))) return true;
+    return false;
+  }
+  static void warn_unknown_names() {
+    static std::atomic<bool> done{false};
+    if (done.exchange(true)) return;
+    extern char **environ;
+    std::string found;
+    for (char **e = environ; e && *e; e++) {
+      if (strncmp(*e, "WANN_", 5) != 0) continue;
+      const char *eq = strchr(*e, '=');
+      const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+      if (!known_name(*e, len)) found += std::string(found.empty() ? "" : ", ") + std::string(*e, len);
+    }
+    if (!found.empty()) fprintf(stderr, "[wann] unknown WANN_* variable(s) in the environment (nothing reads them): %s\n", found.c_str());
+  }
   static Tuning from_env() {
     Tuning t;
+    warn_unknown_names();
     t.hooks_live = on("WANN_TEST_HOOKS");
     t.serialized = on("HIP_LAUNCH_BLOCKING") || on("AMD_SERIALIZE_KERNEL") || on("CUDA_LAUNCH_BLOCKING");
     t.verbose = set("WANN_VERBOSE");

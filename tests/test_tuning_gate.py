@@ -41,3 +41,10 @@ def test_lab_switches_need_the_hooks(tmp_path):
     assert out == ["1", "0", "0", "12", "1", "1", "5.0"] and err == ""
     out, err = _run(tmp_path, {})
     assert out == ["0", "1", "1", "4096", "0", "0", "3.0"] and err == ""
+
+
+def test_unknown_names_are_named_once(tmp_path):
+    """A WANN_* variable nothing reads (a typo, a switch of another version) is named on stderr -- once per process."""
+    out, err = _run(tmp_path, {"WANN_HANDOFF_COMPANION": "1", "WANN_BENCH_CACHE": "/tmp/x", "WANN_VERBOSE": "1"})
+    assert err.count("unknown WANN_* variable") == 1 and "WANN_HANDOFF_COMPANION" in err
+    assert "WANN_BENCH_CACHE" not in err and "WANN_VERBOSE" not in err

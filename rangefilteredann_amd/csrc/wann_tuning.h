@@ -22,6 +22,8 @@
 #include <cstring>
 #include <string>
 
+extern "C" char **environ;  // (POSIX; unistd.h declares it only under _GNU_SOURCE)
+
 namespace wann {
 
 struct Tuning {
@@ -76,9 +78,8 @@ struct Tuning {
   static void warn_unknown_names() {
     static std::atomic<bool> done{false};
     if (done.exchange(true)) return;
-    extern char **environ;
     std::string found;
-    for (char **e = environ; e && *e; e++) {
+    for (char **e = ::environ; e && *e; e++) {
       if (strncmp(*e, "WANN_", 5) != 0) continue;
       const char *eq = strchr(*e, '=');
       const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);

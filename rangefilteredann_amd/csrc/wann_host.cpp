@@ -619,8 +619,9 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
         big.big_cursor = W.ints.p + I_BIG_CURSOR;
         big.g_beam = nullptr;
         big.g_table_bits = hash_bits(with_big_cap);
-        big_lc.blocks = I.num_cus;
+        big_lc.blocks = I.num_cus;  // (cut down to the launch's items + pollers below, once the poller count is known)
         big_lc.waves_per_block = 1;
+        // (filter tables / seen bitmaps for one slot per CU whatever the launch's size: a layout that follows the batch would be re-zeroed -- up to 8 GiB -- whenever it changes)
         ensure_filter_scratch(W.g_table_big, W.g_epoch_big, W.g_seen_big, W.g_table_big_layout, big_lc.blocks, big.g_table_bits, seen_words, st);
         big.g_table = W.g_table_big.p;
         big.g_epoch = W.g_epoch_big.p;
@@ -664,6 +665,15 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
           a.poll_waiting = big.poll_waiting = W.ints.p + I_POLL_WAITING;
           a.done_count = big.done_count = W.ints.p + I_DONE;
           HIP_CHECK(hipMemsetAsync(a.dyn_list, 0xFF, (size_t)W.big_stride * sizeof(int32_t), st));
+        }
+        // As many companion workgroups as the launch has work for: its static items + its pollers.  (Round 6: the launch used to be
+        // one workgroup per CU whatever the batch; started first, all 256 became resident -- half a CU each -- and those without an
+        // item idled as pollers for the whole batch: at 2^-7 of SIFT-1M 122 items + 32 pollers left 102 CUs with ONE ordinary
+        // workgroup instead of two, i.e. 1 093 searches in flight where 1 500 fit, on a launch that is bound by throughput
+        // (profiles/r06_timelines_mid_fractions.txt).  Workgroups that finish their item still join the pollers.)
+        {
+          const int64_t items = (int64_t)W.h_ints[I_BIG_COUNT] + W.h_ints[I_BIG_COUNT + 1];
+          big_lc.blocks = (int)std::max<int64_t>(1, std::min<int64_t>(I.num_cus, items + big.npollers));
         }
       }
       a.g_epoch = nullptr;

@@ -666,11 +666,10 @@ void run_batch(wann_index &I, Workspace &W, hipStream_t side, wann_counters &las
           a.done_count = big.done_count = W.ints.p + I_DONE;
           HIP_CHECK(hipMemsetAsync(a.dyn_list, 0xFF, (size_t)W.big_stride * sizeof(int32_t), st));
         }
-        // As many companion workgroups as the launch has work for: its static items + its pollers.  (Round 6: the launch used to be
-        // one workgroup per CU whatever the batch; started first, all 256 became resident -- half a CU each -- and those without an
-        // item idled as pollers for the whole batch: at 2^-7 of SIFT-1M 122 items + 32 pollers left 102 CUs with ONE ordinary
-        // workgroup instead of two, i.e. 1 093 searches in flight where 1 500 fit, on a launch that is bound by throughput
-        // (profiles/r06_timelines_mid_fractions.txt).  Workgroups that finish their item still join the pollers.)
+        // As many companion workgroups as the launch has work for: its static items + its pollers (round 6; it used to be one
+        // workgroup per CU whatever the batch, the surplus leaving at once or idling as extra pollers).  Workgroups that finish
+        // their item still join the pollers.  Measured same-box: no change of any fraction's batch time beyond noise
+        // (profiles/r06_companion_grid_ab.txt) -- kept because a launch should not ask for 150 KB of LDS 252 times to run 4 pollers.
         {
           const int64_t items = (int64_t)W.h_ints[I_BIG_COUNT] + W.h_ints[I_BIG_COUNT + 1];
           big_lc.blocks = (int)std::max<int64_t>(1, std::min<int64_t>(I.num_cus, items + big.npollers));

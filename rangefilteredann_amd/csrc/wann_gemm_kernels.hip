@@ -1025,7 +1025,7 @@ int launch_gemm_scores(const GemmArgs &a, int num_cus, void *stream) {
     }
     const int slabs = (a.ix.stride + 127) / 128;
     // (four slabs: + the low halves of the last slab's A operand; the overlapped kernel: + its parity arrays and the raw half slab)
-    const bool wide4 = slabs == 4 && WANN_AB != 8;
+    const bool wide4 = slabs == 4;
     const size_t ldsw = (size_t)128 * (4 * 128 + 16) + (wide4 ? 4 : 3) * 128 * 4 + (slabs == 4 ? (size_t)4 * 8 * 64 * 16 : 0) + (wide4 ? (size_t)32 * 1024 : 0);
     void (*kw)(GemmArgs) = slabs == 2 ? k_gemm_scores_wide<2> : slabs == 3 ? k_gemm_scores_wide<3> : wide4 ? k_gemm_scores_wide4 : k_gemm_scores_wide<4>;
     if (gcheck(hipFuncSetAttribute((const void *)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw))) return 1;

@@ -20,9 +20,6 @@ typedef unsigned long long u64;
 #define WANN_PROF_PTR(p) ((unsigned long long *)nullptr)
 #endif
 
-#ifndef WANN_AB
-#define WANN_AB 0  // dev: same-box A/B builds (make EXTRA=-DWANN_AB=n)
-#endif
 #define WANN_LIKELY(x) __builtin_expect(!!(x), 1)
 #define WANN_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
@@ -1944,7 +1941,7 @@ __device__ __forceinline__ float mid_take_distances(const IndexView &ix, int a, 
   // (no registers held across the hop: the compile-time routines where the row shape has one -- a whole row per lane pair in flight,
   // one round trip per pass)
   // (a kernel that holds RowRegs for other row shapes has no room for a second whole row: the lean routines there)
-  if (RowRegsFor<METRIC>::NR == 0 || mode == 0) return wave_distances_own<METRIC, (RowRegsFor<METRIC>::NR != 0 || WANN_AB == 6)>(ix, a, take, qv, row_off);
+  if (RowRegsFor<METRIC>::NR == 0 || mode == 0) return wave_distances_own<METRIC, (RowRegsFor<METRIC>::NR != 0)>(ix, a, take, qv, row_off);
   const int lane = lane_id(), h = lane & 1;
   float mine = 0.f;
   {
@@ -1995,7 +1992,7 @@ __device__ __forceinline__ void wave_beam_search_mid(const IndexView &ix, const 
   u64 *const mb = L.lbeam;
   if (wbits)
     for (int i = lane; i < wwords; i += 64) wbits[i] = 0u;
-  const int mode = NBC > 0 ? NBC : (WANN_AB == 2 || RowRegsFor<METRIC>::NR == 0) ? 0 : uni(row_regs_blocks<METRIC>(ix));  // (blocks of a row a lane holds; 0: rows fetched where they are scored)
+  const int mode = NBC > 0 ? NBC : (RowRegsFor<METRIC>::NR == 0) ? 0 : uni(row_regs_blocks<METRIC>(ix));  // (blocks of a row a lane holds; 0: rows fetched where they are scored)
   const int lim = uni(limit > 0x7fffffff ? 0x7fffffff : (int)limit);
 
   // frontier = {start node 0} (beamSearch.h:80-82)

@@ -765,7 +765,7 @@ def config_traffic(name, setting):
         except Exception:
             continue
         if setting is None or (pj.get("beam") == setting.get("beam") and pj.get("mult") == setting.get("mult")):
-            best = (pj.get("hbm_bytes_per_launch"), f"profiles/{fn} (kernel {pj.get('kernel')}; separate rocprofv3 --pmc FETCH_SIZE pass of this leg, not this run)")
+            best = (pj.get("hbm_bytes_per_launch"), f"profiles/{fn} (kernel {pj.get('kernel')}; separate rocprofv3 --pmc FETCH_SIZE pass of this leg, not this run; dispatches serialised under --pmc)")
     return best
 
 
@@ -797,7 +797,7 @@ def measured_traffic(beam, mult, n, nq_per_gpu, fraction=-3):
         # (a fraction whose windows all take the exact scan moves the same bytes at every setting)
         if (((pj.get("beam") == beam and pj.get("mult") == mult) or pj.get("scan_only")) and pj.get("n") == n and pj.get("nq", 10_000) == nq_per_gpu
                 and pj.get("fraction", -3) == fraction):
-            best = (pj.get("hbm_bytes_per_launch"), f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE pass of this configuration, not this run)")
+            best = (pj.get("hbm_bytes_per_launch"), f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE pass of this configuration, not this run; --pmc serialises dispatches: the batch's bytes, not the concurrent launches' timing)")
     return best if best else (None, None)
 
 
